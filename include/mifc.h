@@ -1,0 +1,180 @@
+/*
+ * mifc.h -- C ABI of the MI355X (gfx950) implementation of the mi-fieldcalc
+ * hot path: the elementwise derived-variable operators and the horizontal
+ * 5-point-stencil operators of miutil::fieldcalc.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer of its own:
+ * its operator API is the set of C++ free functions declared in
+ * src/mi_fieldcalc/FieldCalculations.h.  Each entry point below replaces one
+ * of them (file:line cited per function) with the same argument order
+ *   nx, ny, input fields, scalars ("compute" last), output field(s),
+ *   fDefined (in/out), undef                      (FieldCalculations.h:102-107)
+ * plus a leading context and a trailing `memkind`.  The source-compatible C++
+ * header mi-fieldcalc_amd/include/mi_fieldcalc/FieldCalculations.h forwards
+ * the original signatures to these; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - fields are row-major float32, index = j*nx + i, x fastest
+ *     (FieldCalculations.cc:65-73); batched calls take [nlev][ny][nx]
+ *     contiguous, level-major.
+ *   - `int* fdefined` carries miutil::ValuesDefined (FieldDefined.h:41) and is
+ *     IN/OUT exactly as in the reference: in = state of the inputs
+ *     (MIFC_ALL_DEFINED enables the no-test fast path, FieldCalculations.h:47-50),
+ *     out = state of the result (FieldDefined.cc:62-70).  Always host memory.
+ *   - return value: 1 = success, 0 = the reference's `return false`
+ *     (bad sizes / compute / pressure) or a HIP failure; in the latter case
+ *     mifc_last_error() is non-empty.  Nothing throws across this boundary.
+ *   - memkind says where the FIELD pointers live: MIFC_MEM_HOST (legacy
+ *     callers: staged through the context's device scratch, synchronous) or
+ *     MIFC_MEM_DEVICE (resident in HBM, no copies; the call still returns
+ *     only after the result flag is known).  The *_enqueue variants never
+ *     synchronise.
+ *   - every operator body is a hand-written HIP kernel; there is no CPU
+ *     fallback.  Without a usable gfx950 device mifc_create() returns NULL.
+ *   - in-place use (output aliasing an input) is supported for the
+ *     elementwise operators only, as in the reference.
+ */
+#ifndef MIFC_H
+#define MIFC_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIFC_ABI_VERSION 1
+
+/* miutil::ValuesDefined, FieldDefined.h:41 */
+enum { MIFC_ALL_DEFINED = 0, MIFC_NONE_DEFINED = 1, MIFC_SOME_DEFINED = 2 };
+enum { MIFC_MEM_HOST = 0, MIFC_MEM_DEVICE = 1 };
+
+typedef struct mifc_ctx mifc_ctx;
+
+/* ---- context ------------------------------------------------------------ */
+int mifc_abi_version(void);
+/* number of visible HIP devices (0 when there is no GPU / no driver) */
+int mifc_device_count(void);
+/* Binds to HIP device `device`; owns a stream, scratch and staging buffers.
+ * NULL on failure.  A context may be used from one thread at a time; create
+ * one per thread for concurrent callers (the reference is re-entrant). */
+mifc_ctx* mifc_create(int device);
+void mifc_destroy(mifc_ctx* ctx);
+const char* mifc_last_error(const mifc_ctx* ctx);
+/* Run subsequent work on a caller-owned hipStream_t (e.g. the PyTorch current
+ * stream); NULL switches back to the context's own stream. */
+int mifc_set_stream(mifc_ctx* ctx, void* hip_stream);
+int mifc_synchronize(mifc_ctx* ctx);
+/* Device memory for callers that do not link HIP themselves. */
+void* mifc_device_alloc(mifc_ctx* ctx, size_t bytes);
+int mifc_device_free(mifc_ctx* ctx, void* dptr);
+int mifc_copy_to_device(mifc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int mifc_copy_to_host(mifc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* miutil::checkDefined(size_t,size_t), FieldDefined.cc:62-70 */
+int mifc_classify(unsigned long long n_undefined, unsigned long long n);
+
+/* ---- elementwise, one field per call ------------------------------------ */
+/* miutil::fieldcalc::vectorabs, FieldCalculations.h:204 / FieldCalculations.cc:1819 */
+int mifc_vectorabs(mifc_ctx* ctx, int nx, int ny, const float* u, const float* v, float* ff, int* fdefined, float undef, int memkind);
+/* pleveltemp FieldCalculations.h:113 / .cc:328; hleveltemp .h:154 / .cc:1046; aleveltemp .h:172 / .cc:1310 */
+int mifc_pleveltemp(mifc_ctx* ctx, int nx, int ny, const float* tinp, float p, const char* unit, int compute, float* tout, int* fdefined,
+                    float undef, int memkind);
+int mifc_hleveltemp(mifc_ctx* ctx, int nx, int ny, const float* tinp, const float* ps, float alevel, float blevel, const char* unit, int compute,
+                    float* tout, int* fdefined, float undef, int memkind);
+int mifc_aleveltemp(mifc_ctx* ctx, int nx, int ny, const float* tinp, const float* p, const char* unit, int compute, float* tout, int* fdefined,
+                    float undef, int memkind);
+/* plevelhum FieldCalculations.h:117 / .cc:400; hlevelhum .h:160 / .cc:1145; alevelhum .h:176 / .cc:1394; cvhum .h:200 / .cc:1738 */
+int mifc_plevelhum(mifc_ctx* ctx, int nx, int ny, const float* t, const float* huminp, float p, const char* unit, int compute, float* humout,
+                   int* fdefined, float undef, int memkind);
+int mifc_hlevelhum(mifc_ctx* ctx, int nx, int ny, const float* t, const float* huminp, const float* ps, float alevel, float blevel,
+                   const char* unit, int compute, float* humout, int* fdefined, float undef, int memkind);
+int mifc_alevelhum(mifc_ctx* ctx, int nx, int ny, const float* t, const float* huminp, const float* p, const char* unit, int compute,
+                   float* humout, int* fdefined, float undef, int memkind);
+int mifc_cvhum(mifc_ctx* ctx, int nx, int ny, const float* t, const float* huminp, const char* unit, int compute, float* humout, int* fdefined,
+               float undef, int memkind);
+
+/* ---- 5-point stencils, one field per call ------------------------------- */
+/* relvort FieldCalculations.h:206 / .cc:1843; absvort .h:208 / .cc:1875; divergence .h:211 / .cc:1910 */
+int mifc_relvort(mifc_ctx* ctx, int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr, float* rvort,
+                 int* fdefined, float undef, int memkind);
+int mifc_absvort(mifc_ctx* ctx, int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr, const float* fcoriolis,
+                 float* avort, int* fdefined, float undef, int memkind);
+int mifc_divergence(mifc_ctx* ctx, int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr, float* diverg,
+                    int* fdefined, float undef, int memkind);
+/* gradient FieldCalculations.h:216 / .cc:1985 (compute 1..4) */
+int mifc_gradient(mifc_ctx* ctx, int nx, int ny, const float* field, const float* xmapr, const float* ymapr, int compute, float* fgrad,
+                  int* fdefined, float undef, int memkind);
+/* plevelgwind_xcomp .h:127 / .cc:638; plevelgwind_ycomp .h:130 / .cc:674; plevelgvort .h:133 / .cc:708 */
+int mifc_plevelgwind_xcomp(mifc_ctx* ctx, int nx, int ny, const float* z, const float* xmapr, const float* ymapr, const float* fcoriolis, float* ug,
+                           int* fdefined, float undef, int memkind);
+int mifc_plevelgwind_ycomp(mifc_ctx* ctx, int nx, int ny, const float* z, const float* xmapr, const float* ymapr, const float* fcoriolis, float* vg,
+                           int* fdefined, float undef, int memkind);
+int mifc_plevelgvort(mifc_ctx* ctx, int nx, int ny, const float* z, const float* xmapr, const float* ymapr, const float* fcoriolis, float* gvort,
+                     int* fdefined, float undef, int memkind);
+/* ilevelgwind FieldCalculations.h:185 / .cc:1511 */
+int mifc_ilevelgwind(mifc_ctx* ctx, int nx, int ny, const float* mpot, const float* xmapr, const float* ymapr, const float* fcoriolis, float* ug,
+                     float* vg, int* fdefined, float undef, int memkind);
+
+/* ---- batched over vertical levels / ensemble members (new surface) ------ */
+/* The reference is called once per 2-D field; a caller that wants vorticity
+ * AND divergence on nlev levels makes 2*nlev calls.  These
+ * entry points do the same work in one fused pass per level-batch.
+ *
+ * u, v, rvort, diverg : [nlev][ny][nx];  xmapr, ymapr (, fcoriolis) : [ny][nx],
+ * shared by all levels.  rvort or diverg may be NULL to skip that output.
+ * fdefined : host int[nlev], in = input state per level, out = state of the
+ * result(s) of that level -- identical for rvort and diverg because
+ * FieldCalculations.cc:1861 and :1927 test the same four neighbours.
+ * Result per level is bit-identical to relvort()+divergence() on that level. */
+int mifc_vortdiv_levels(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
+                        float* rvort, float* diverg, int* fdefined, float undef, int memkind);
+/* Asynchronous form, device pointers only: enqueues on the context's stream
+ * and returns.  `fdefined_in` (host int[nlev], may be NULL = all
+ * MIFC_SOME_DEFINED) is read before returning.  `n_undefined_dev` is a device
+ * array of nlev 64-bit counters that the call zeroes and the kernel fills;
+ * classify each against (nx*ny - 2*nx) with mifc_classify() once the stream
+ * has drained.  It may be NULL when every level is MIFC_ALL_DEFINED. */
+int mifc_vortdiv_levels_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
+                                float* rvort, float* diverg, const int* fdefined_in, float undef, unsigned long long* n_undefined_dev);
+
+/* Fused derived variables on hybrid model levels: one pass producing any of
+ *   ff    = vectorabs(u, v)                                   (.cc:1819)
+ *   rh    = hlevelhum(t, q, ps, a, b, "", compute=1)  RH in %   (.cc:1145)
+ *   theta = hleveltemp(t, ps, a, b, "", compute=3)  T -> theta  (.cc:1046)
+ * u, v, t, q, ff, rh, theta : [nlev][ny][nx]; ps : [ny][nx] shared;
+ * alevel, blevel : host float[nlev].  Any of ff / rh / theta may be NULL
+ * (its inputs are then not read).  fdef_wind / fdef_thermo : host int[nlev]
+ * input states of (u,v) and of (t,q,ps); outputs fdef_ff, fdef_rh, fdef_theta
+ * : host int[nlev].  Returns 0 if any level has a bad (a,b) pair (.cc:298). */
+int mifc_hlevel_derived_levels(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q,
+                               const float* ps, const float* alevel, const float* blevel, float* ff, float* rh, float* theta,
+                               const int* fdef_wind, const int* fdef_thermo, int* fdef_ff, int* fdef_rh, int* fdef_theta, float undef,
+                               int memkind);
+/* Asynchronous, device pointers only.  n_undefined_dev: device u64[3*nlev]
+ * laid out [ff | rh | theta], zeroed by the call; classify against nx*ny. */
+int mifc_hlevel_derived_levels_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q,
+                                       const float* ps, const float* alevel, const float* blevel, float* ff, float* rh, float* theta,
+                                       const int* fdef_wind, const int* fdef_thermo, float undef, unsigned long long* n_undefined_dev);
+
+/* ---- horizontally decomposed single field (row slabs) -------------------- */
+/* Vorticity + divergence on one row slab of a larger field (config 4 of
+ * BASELINE.json: a 4000x4000 field split over 8 GPUs along y).
+ * The slab holds `ny_local` owned rows starting at global row `j0` of a field
+ * with `ny_global` rows; u and v point at [ny_local + 2][nx] buffers whose
+ * first and last rows are the halo rows (global rows j0-1 and j0+ny_local)
+ * filled by the caller's exchange (RCCL send/recv over xGMI; halo content is
+ * ignored where it would fall outside the global field).  xmapr, ymapr,
+ * rvort, diverg : [ny_local][nx], owned rows only.  The global edge rules of
+ * fillEdges (FieldCalculations.cc:59-74) are applied by whichever slab owns
+ * the edge rows.  *n_undefined_dev (device u64[1], zeroed by the call)
+ * receives this slab's share of the global undefined count; the sum over
+ * slabs classifies against nx*ny_global - 2*nx.  Asynchronous, device only. */
+int mifc_vortdiv_slab_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int ny_local, const float* u_halo, const float* v_halo,
+                              const float* xmapr, const float* ymapr, float* rvort, float* diverg, int fdefined_in, float undef,
+                              unsigned long long* n_undefined_dev);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MIFC_H */

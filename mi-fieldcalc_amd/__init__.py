@@ -1,0 +1,311 @@
+"""mi_fieldcalc_amd -- MI355X (gfx950) implementation of the mi-fieldcalc hot
+path: the elementwise derived-variable operators and the 5-point-stencil
+operators of ``miutil::fieldcalc`` (reference: src/mi_fieldcalc/FieldCalculations.h).
+
+This Python layer is plumbing over the C ABI in ``include/mifc.h``: it picks
+pointers out of numpy arrays (host memory, the legacy calling convention) or
+PyTorch CUDA tensors (fields resident in HBM), forwards to ``libmifc.so`` and
+hands back ``(result, fDefined)``.  Operator names, argument order and failure
+behaviour follow the reference: where the C++ function returns ``false`` the
+wrapper returns ``None`` (as the reference's pybind11 layer does,
+python/py_mi_fieldcalc.cc:92-93).
+
+There is no CPU compute path here.  Without the HIP library the import fails,
+without a GPU ``Context()`` raises.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _capi
+
+ALL_DEFINED, NONE_DEFINED, SOME_DEFINED = 0, 1, 2  # miutil::ValuesDefined, FieldDefined.h:41
+UNDEF = np.float32(1.0e35)  # miutil::UNDEF, FieldDefined.cc:34
+MEM_HOST, MEM_DEVICE = 0, 1
+
+__all__ = ["Context", "ALL_DEFINED", "NONE_DEFINED", "SOME_DEFINED", "UNDEF", "classify"]
+
+
+def classify(n_undefined, n):
+    """miutil::checkDefined(size_t, size_t), FieldDefined.cc:62-70."""
+    return _capi.lib().mifc_classify(int(n_undefined), int(n))
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class _Arg:
+    """Address + keep-alive of one field argument."""
+
+    __slots__ = ("addr", "keep", "device", "shape")
+
+    def __init__(self, x, allow_none=False):
+        if x is None:
+            if not allow_none:
+                raise ValueError("missing field argument")
+            self.addr, self.keep, self.device, self.shape = None, None, None, None
+            return
+        if _is_torch(x):
+            import torch
+
+            if x.dtype != torch.float32 or not x.is_contiguous():
+                raise ValueError("device fields must be contiguous float32 tensors")
+            if not x.is_cuda:
+                raise ValueError("torch tensors must live on the GPU; pass numpy arrays for host memory")
+            self.addr, self.keep, self.device, self.shape = x.data_ptr(), x, True, tuple(x.shape)
+        else:
+            a = np.ascontiguousarray(x, dtype=np.float32)  # forcecast, like py_mi_fieldcalc.cc:40
+            self.addr, self.keep, self.device, self.shape = a.ctypes.data, a, False, a.shape
+
+
+def _memkind(args):
+    kinds = {a.device for a in args if a.addr is not None}
+    if len(kinds) != 1:
+        raise ValueError("all fields of one call must be either numpy (host) or CUDA tensors (device)")
+    return MEM_DEVICE if kinds.pop() else MEM_HOST
+
+
+def _empty_like(ref, shape=None):
+    if _is_torch(ref):
+        import torch
+
+        return torch.empty(shape or ref.shape, dtype=torch.float32, device=ref.device)
+    return np.empty(shape or np.shape(ref), dtype=np.float32)
+
+
+class Context:
+    """One mifc_ctx: a HIP device, a stream, staging scratch.  Not thread-safe;
+    create one per thread (the reference is re-entrant)."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = _capi.lib()
+        self._ctx = self._lib.mifc_create(int(device))
+        if not self._ctx:
+            raise RuntimeError(
+                "mifc_create(%d) failed: no usable HIP device (visible devices: %d). "
+                "The operators run on the GPU only; there is no CPU fallback." % (device, self._lib.mifc_device_count())
+            )
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.mifc_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ misc
+    def last_error(self):
+        s = self._lib.mifc_last_error(self._ctx)
+        return s.decode() if s else ""
+
+    def set_stream(self, stream):
+        """stream: raw hipStream_t address, a torch.cuda.Stream, or None."""
+        if stream is not None and hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        self._lib.mifc_set_stream(self._ctx, ctypes.c_void_p(stream or 0))
+
+    def use_torch_stream(self):
+        import torch
+
+        self.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def synchronize(self):
+        if not self._lib.mifc_synchronize(self._ctx):
+            raise RuntimeError(self.last_error())
+
+    # ------------------------------------------------------------ call helper
+    def _call(self, name, args):
+        rc = getattr(self._lib, name)(self._ctx, *args)
+        if not rc and self.last_error():
+            err = self.last_error()
+            raise RuntimeError("%s: %s" % (name, err))
+        return rc
+
+    @staticmethod
+    def _nxny(a):
+        ny, nx = a.shape[-2], a.shape[-1]
+        return nx, ny
+
+    def _single(self, name, fields, scalars, outs, fdefined, undef, n_out=1, out_like=None):
+        """fields: input arrays (None allowed), scalars: list placed between
+        inputs and outputs in reference order, outs: preallocated or None."""
+        fa = [_Arg(f, allow_none=True) for f in fields]
+        ref = next(f for f in fields if f is not None)
+        nx, ny = self._nxny(_Arg(ref))
+        outs = list(outs)
+        for k in range(n_out):
+            if outs[k] is None:
+                outs[k] = _empty_like(ref)
+        oa = [_Arg(o) for o in outs]
+        mk = _memkind(fa + oa)
+        fd = ctypes.c_int(int(fdefined))
+        args = [nx, ny] + [a.addr for a in fa] + list(scalars) + [a.addr for a in oa] + [ctypes.addressof(fd), float(undef), mk]
+        if not self._call(name, args):
+            return None
+        res = [o if _is_torch(o) else a.keep for o, a in zip(outs, oa)]
+        return (res[0] if n_out == 1 else tuple(res)), fd.value
+
+    # ---------------------------------------------------- elementwise operators
+    def vectorabs(self, u, v, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        """ff = sqrt(u*u+v*v); FieldCalculations.cc:1819."""
+        return self._single("mifc_vectorabs", [u, v], [], [out], fdefined, undef)
+
+    def pleveltemp(self, tinp, p, unit, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_pleveltemp", [tinp], [float(p), unit.encode(), int(compute)], [out], fdefined, undef)
+
+    def hleveltemp(self, tinp, ps, alevel, blevel, unit, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single(
+            "mifc_hleveltemp", [tinp, ps], [float(alevel), float(blevel), unit.encode(), int(compute)], [out], fdefined, undef
+        )
+
+    def aleveltemp(self, tinp, p, unit, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_aleveltemp", [tinp, p], [unit.encode(), int(compute)], [out], fdefined, undef)
+
+    def plevelhum(self, t, huminp, p, unit, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_plevelhum", [t, huminp], [float(p), unit.encode(), int(compute)], [out], fdefined, undef)
+
+    def hlevelhum(self, t, huminp, ps, alevel, blevel, unit, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single(
+            "mifc_hlevelhum", [t, huminp, ps], [float(alevel), float(blevel), unit.encode(), int(compute)], [out], fdefined, undef
+        )
+
+    def alevelhum(self, t, huminp, p, unit, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_alevelhum", [t, huminp, p], [unit.encode(), int(compute)], [out], fdefined, undef)
+
+    def cvhum(self, t, huminp, unit, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_cvhum", [t, huminp], [unit.encode(), int(compute)], [out], fdefined, undef)
+
+    # -------------------------------------------------------- stencil operators
+    def relvort(self, u, v, xmapr, ymapr, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_relvort", [u, v, xmapr, ymapr], [], [out], fdefined, undef)
+
+    def absvort(self, u, v, xmapr, ymapr, fcoriolis, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_absvort", [u, v, xmapr, ymapr, fcoriolis], [], [out], fdefined, undef)
+
+    def divergence(self, u, v, xmapr, ymapr, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_divergence", [u, v, xmapr, ymapr], [], [out], fdefined, undef)
+
+    def gradient(self, field, xmapr, ymapr, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_gradient", [field, xmapr, ymapr], [int(compute)], [out], fdefined, undef)
+
+    def plevelgwind_xcomp(self, z, xmapr, ymapr, fcoriolis, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_plevelgwind_xcomp", [z, xmapr, ymapr, fcoriolis], [], [out], fdefined, undef)
+
+    def plevelgwind_ycomp(self, z, xmapr, ymapr, fcoriolis, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_plevelgwind_ycomp", [z, xmapr, ymapr, fcoriolis], [], [out], fdefined, undef)
+
+    def plevelgvort(self, z, xmapr, ymapr, fcoriolis, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_plevelgvort", [z, xmapr, ymapr, fcoriolis], [], [out], fdefined, undef)
+
+    def ilevelgwind(self, mpot, xmapr, ymapr, fcoriolis, fdefined=SOME_DEFINED, undef=UNDEF, out=(None, None)):
+        return self._single("mifc_ilevelgwind", [mpot, xmapr, ymapr, fcoriolis], [], list(out), fdefined, undef, n_out=2)
+
+    # ------------------------------------------------------------------ batched
+    def vortdiv_levels(self, u, v, xmapr, ymapr, fdefined=None, undef=UNDEF, rvort=None, diverg=None, want=("rvort", "diverg")):
+        """Fused relvort + divergence over u, v of shape (nlev, ny, nx).
+        fdefined: int sequence per level (default SOME_DEFINED).  Returns
+        ((rvort, diverg), flags ndarray) or None."""
+        au, av, ax, ay = _Arg(u), _Arg(v), _Arg(xmapr), _Arg(ymapr)
+        if len(au.shape) != 3:
+            raise ValueError("u, v must have shape (nlev, ny, nx)")
+        nlev, ny, nx = au.shape
+        if rvort is None and "rvort" in want:
+            rvort = _empty_like(u)
+        if diverg is None and "diverg" in want:
+            diverg = _empty_like(u)
+        ar, ad = _Arg(rvort, allow_none=True), _Arg(diverg, allow_none=True)
+        mk = _memkind([au, av, ax, ay, ar, ad])
+        flags = np.full(nlev, SOME_DEFINED, dtype=np.int32) if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
+        rc = self._call(
+            "mifc_vortdiv_levels",
+            [nx, ny, nlev, au.addr, av.addr, ax.addr, ay.addr, ar.addr, ad.addr, flags.ctypes.data, float(undef), mk],
+        )
+        if not rc:
+            return None
+        outs = tuple(o if (o is None or _is_torch(o)) else a.keep for o, a in ((rvort, ar), (diverg, ad)))
+        return outs, flags
+
+    def vortdiv_levels_enqueue(self, u, v, xmapr, ymapr, rvort, diverg, fdefined=None, undef=UNDEF, n_undefined=None):
+        """Asynchronous form on device tensors; n_undefined: int64 CUDA tensor[nlev] or None."""
+        au, av, ax, ay = _Arg(u), _Arg(v), _Arg(xmapr), _Arg(ymapr)
+        ar, ad = _Arg(rvort, allow_none=True), _Arg(diverg, allow_none=True)
+        nlev, ny, nx = au.shape
+        flags = None if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
+        rc = self._call(
+            "mifc_vortdiv_levels_enqueue",
+            [
+                nx, ny, nlev, au.addr, av.addr, ax.addr, ay.addr, ar.addr, ad.addr,
+                None if flags is None else flags.ctypes.data, float(undef),
+                None if n_undefined is None else n_undefined.data_ptr(),
+            ],
+        )
+        return bool(rc)
+
+    def hlevel_derived_levels(self, u, v, t, q, ps, alevel, blevel, fdef_wind=None, fdef_thermo=None, undef=UNDEF,
+                              want=("ff", "rh", "theta"), out=None):
+        """Fused ff / RH(%) / theta on hybrid levels; u, v, t, q: (nlev, ny, nx), ps: (ny, nx).
+        Returns ({name: array}, {name: flags}) or None."""
+        ref = next(x for x in (u, t) if x is not None)
+        nlev, ny, nx = _Arg(ref).shape
+        out = dict(out or {})
+        for k in want:
+            if out.get(k) is None:
+                out[k] = _empty_like(ref)
+        a = {k: _Arg(x, allow_none=True) for k, x in dict(u=u, v=v, t=t, q=q, ps=ps).items()}
+        o = {k: _Arg(out.get(k), allow_none=True) for k in ("ff", "rh", "theta")}
+        mk = _memkind(list(a.values()) + list(o.values()))
+        al = np.ascontiguousarray(alevel if alevel is not None else np.zeros(nlev), dtype=np.float32).reshape(nlev)
+        bl = np.ascontiguousarray(blevel if blevel is not None else np.ones(nlev), dtype=np.float32).reshape(nlev)
+        fw = np.full(nlev, SOME_DEFINED, np.int32) if fdef_wind is None else np.array(fdef_wind, np.int32).reshape(nlev).copy()
+        ft = np.full(nlev, SOME_DEFINED, np.int32) if fdef_thermo is None else np.array(fdef_thermo, np.int32).reshape(nlev).copy()
+        fo = {k: np.full(nlev, -1, np.int32) for k in ("ff", "rh", "theta")}
+        rc = self._call(
+            "mifc_hlevel_derived_levels",
+            [
+                nx, ny, nlev, a["u"].addr, a["v"].addr, a["t"].addr, a["q"].addr, a["ps"].addr, al.ctypes.data, bl.ctypes.data,
+                o["ff"].addr, o["rh"].addr, o["theta"].addr, fw.ctypes.data, ft.ctypes.data,
+                fo["ff"].ctypes.data, fo["rh"].ctypes.data, fo["theta"].ctypes.data, float(undef), mk,
+            ],
+        )
+        if not rc:
+            return None
+        res = {k: (out[k] if _is_torch(out[k]) else o[k].keep) for k in want}
+        return res, {k: fo[k] for k in want}
+
+    def hlevel_derived_levels_enqueue(self, u, v, t, q, ps, alevel, blevel, ff, rh, theta, n_undefined, fdef_wind=None,
+                                      fdef_thermo=None, undef=UNDEF):
+        ref = next(x for x in (u, t) if x is not None)
+        nlev, ny, nx = _Arg(ref).shape
+        a = [_Arg(x, allow_none=True) for x in (u, v, t, q, ps)]
+        o = [_Arg(x, allow_none=True) for x in (ff, rh, theta)]
+        al = np.ascontiguousarray(alevel, dtype=np.float32).reshape(nlev)
+        bl = np.ascontiguousarray(blevel, dtype=np.float32).reshape(nlev)
+        fw = None if fdef_wind is None else np.array(fdef_wind, np.int32).reshape(nlev).copy()
+        ft = None if fdef_thermo is None else np.array(fdef_thermo, np.int32).reshape(nlev).copy()
+        rc = self._call(
+            "mifc_hlevel_derived_levels_enqueue",
+            [nx, ny, nlev] + [x.addr for x in a] + [al.ctypes.data, bl.ctypes.data] + [x.addr for x in o]
+            + [None if fw is None else fw.ctypes.data, None if ft is None else ft.ctypes.data, float(undef), n_undefined.data_ptr()],
+        )
+        return bool(rc)
+
+    def vortdiv_slab_enqueue(self, nx, ny_global, j0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, fdefined_in=SOME_DEFINED,
+                             undef=UNDEF, n_undefined=None):
+        """Row-slab form (see include/mifc.h); all tensors on the device."""
+        a = [_Arg(x, allow_none=True) for x in (u_halo, v_halo, xmapr, ymapr, rvort, diverg)]
+        rc = self._call(
+            "mifc_vortdiv_slab_enqueue",
+            [int(nx), int(ny_global), int(j0), int(ny_local)] + [x.addr for x in a]
+            + [int(fdefined_in), float(undef), None if n_undefined is None else n_undefined.data_ptr()],
+        )
+        return bool(rc)

@@ -1,0 +1,97 @@
+"""ctypes binding of the C ABI declared in include/mifc.h.
+
+Loading never falls back to anything: if ``libmifc.so`` (the HIP build for
+gfx950) is missing, importing this module raises.  Computing additionally needs
+a GPU: ``mifc_create`` returns NULL without one and ``Context`` raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmifc.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+c_u64_p = ctypes.POINTER(ctypes.c_ulonglong)
+
+_T = {
+    "ctx": ctypes.c_void_p,
+    "i": ctypes.c_int,
+    "f": ctypes.c_float,
+    "s": ctypes.c_char_p,
+    "p": ctypes.c_void_p,  # float* (host or device), passed as an address
+    "pi": ctypes.c_void_p,  # int*  (host)
+    "pu": ctypes.c_void_p,  # unsigned long long* (device)
+    "z": ctypes.c_size_t,
+    "u64": ctypes.c_ulonglong,
+}
+
+# name -> (restype, [argument kinds]); mirrors include/mifc.h one to one
+SIGNATURES = {
+    "mifc_abi_version": ("i", []),
+    "mifc_device_count": ("i", []),
+    "mifc_create": ("ctx", ["i"]),
+    "mifc_destroy": (None, ["ctx"]),
+    "mifc_last_error": ("s", ["ctx"]),
+    "mifc_set_stream": ("i", ["ctx", "p"]),
+    "mifc_synchronize": ("i", ["ctx"]),
+    "mifc_device_alloc": ("p", ["ctx", "z"]),
+    "mifc_device_free": ("i", ["ctx", "p"]),
+    "mifc_copy_to_device": ("i", ["ctx", "p", "p", "z"]),
+    "mifc_copy_to_host": ("i", ["ctx", "p", "p", "z"]),
+    "mifc_classify": ("i", ["u64", "u64"]),
+    # elementwise
+    "mifc_vectorabs": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_pleveltemp": ("i", ["ctx", "i", "i", "p", "f", "s", "i", "p", "pi", "f", "i"]),
+    "mifc_hleveltemp": ("i", ["ctx", "i", "i", "p", "p", "f", "f", "s", "i", "p", "pi", "f", "i"]),
+    "mifc_aleveltemp": ("i", ["ctx", "i", "i", "p", "p", "s", "i", "p", "pi", "f", "i"]),
+    "mifc_plevelhum": ("i", ["ctx", "i", "i", "p", "p", "f", "s", "i", "p", "pi", "f", "i"]),
+    "mifc_hlevelhum": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "f", "s", "i", "p", "pi", "f", "i"]),
+    "mifc_alevelhum": ("i", ["ctx", "i", "i", "p", "p", "p", "s", "i", "p", "pi", "f", "i"]),
+    "mifc_cvhum": ("i", ["ctx", "i", "i", "p", "p", "s", "i", "p", "pi", "f", "i"]),
+    # stencils
+    "mifc_relvort": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_absvort": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_divergence": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_gradient": ("i", ["ctx", "i", "i", "p", "p", "p", "i", "p", "pi", "f", "i"]),
+    "mifc_plevelgwind_xcomp": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_plevelgwind_ycomp": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_plevelgvort": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_ilevelgwind": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    # batched
+    "mifc_vortdiv_levels": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_vortdiv_levels_enqueue": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "pu"]),
+    "mifc_hlevel_derived_levels": (
+        "i",
+        ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "p", "pi", "pi", "pi", "pi", "pi", "f", "i"],
+    ),
+    "mifc_hlevel_derived_levels_enqueue": (
+        "i",
+        ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "p", "pi", "pi", "f", "pu"],
+    ),
+    "mifc_vortdiv_slab_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu"]),
+}
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C mi-fieldcalc_amd). There is no CPU fallback." % path
+        )
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = _T[res] if res else None
+        fn.argtypes = [_T[a] for a in args]
+    return lib
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = load_library()
+    return _lib

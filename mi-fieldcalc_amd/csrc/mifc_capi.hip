@@ -1,0 +1,1043 @@
+// mifc_capi.hip -- the extern "C" boundary declared in include/mifc.h.
+//
+// Host-side logic only: argument validation exactly as the reference does it
+// (what makes an operator `return false`), the unit/compute remaps, staging of
+// legacy host pointers through device scratch, launching the HIP kernels and
+// turning the per-field undefined counts into ValuesDefined flags.  There is
+// no CPU compute path: every operator body runs on the GPU.
+#include "../../include/mifc.h"
+#include "mifc_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using mifc::u64;
+
+struct mifc_ctx
+{
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // grow-only device scratch slots for staged host fields
+  static const int NSLOT = 10;
+  void* slot[NSLOT] = {nullptr};
+  size_t slot_bytes[NSLOT] = {0};
+  // per-level flags / counters
+  unsigned char* d_flags = nullptr; // 2 * cap_lev bytes (wind | thermo, or just one set)
+  u64* d_counts = nullptr;          // 3 * cap_lev
+  float* d_ab = nullptr;            // 2 * cap_lev (alevel | blevel)
+  void* h_pinned = nullptr;         // pinned mirror: counts (3*cap u64) + flags (2*cap) + ab (2*cap float)
+  size_t cap_lev = 0;
+  // recorded after every async copy that READS the pinned mirror (enqueue
+  // variants); waited on before the mirror is rewritten
+  hipEvent_t pinned_read = nullptr;
+  bool pinned_read_pending = false;
+};
+
+namespace {
+
+bool fail(mifc_ctx* c, const char* what, hipError_t e)
+{
+  char buf[256];
+  std::snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  if (c)
+    c->err = buf;
+  return false;
+}
+
+#define MIFC_HIP(c, call)                    \
+  do {                                       \
+    hipError_t e_ = (call);                  \
+    if (e_ != hipSuccess) {                  \
+      fail((c), #call, e_);                  \
+      return 0;                              \
+    }                                        \
+  } while (0)
+
+bool ensure_slot(mifc_ctx* c, int s, size_t bytes)
+{
+  if (c->slot_bytes[s] >= bytes)
+    return true;
+  if (c->slot[s]) {
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess)
+      return fail(c, "hipStreamSynchronize", e);
+    (void)hipFree(c->slot[s]);
+    c->slot[s] = nullptr;
+    c->slot_bytes[s] = 0;
+  }
+  const size_t want = (bytes + 255) & ~size_t(255);
+  hipError_t e = hipMalloc(&c->slot[s], want);
+  if (e != hipSuccess)
+    return fail(c, "hipMalloc(scratch)", e);
+  c->slot_bytes[s] = want;
+  return true;
+}
+
+bool ensure_levels(mifc_ctx* c, size_t nlev)
+{
+  if (c->cap_lev >= nlev)
+    return true;
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess)
+    return fail(c, "hipStreamSynchronize", e);
+  if (c->d_flags)
+    (void)hipFree(c->d_flags);
+  if (c->d_counts)
+    (void)hipFree(c->d_counts);
+  if (c->d_ab)
+    (void)hipFree(c->d_ab);
+  if (c->h_pinned)
+    (void)hipHostFree(c->h_pinned);
+  c->d_flags = nullptr;
+  c->d_counts = nullptr;
+  c->d_ab = nullptr;
+  c->h_pinned = nullptr;
+  c->cap_lev = 0;
+  size_t cap = 256;
+  while (cap < nlev)
+    cap *= 2;
+  if ((e = hipMalloc((void**)&c->d_flags, 2 * cap)) != hipSuccess)
+    return fail(c, "hipMalloc(flags)", e);
+  if ((e = hipMalloc((void**)&c->d_counts, 3 * cap * sizeof(u64))) != hipSuccess)
+    return fail(c, "hipMalloc(counts)", e);
+  if ((e = hipMalloc((void**)&c->d_ab, 2 * cap * sizeof(float))) != hipSuccess)
+    return fail(c, "hipMalloc(ab)", e);
+  if ((e = hipHostMalloc(&c->h_pinned, 3 * cap * sizeof(u64) + 2 * cap + 2 * cap * sizeof(float), hipHostMallocDefault)) != hipSuccess)
+    return fail(c, "hipHostMalloc", e);
+  c->cap_lev = cap;
+  return true;
+}
+
+bool pinned_acquire(mifc_ctx* c)
+{
+  if (c->pinned_read_pending) {
+    hipError_t e = hipEventSynchronize(c->pinned_read);
+    if (e != hipSuccess)
+      return fail(c, "hipEventSynchronize", e);
+    c->pinned_read_pending = false;
+  }
+  return true;
+}
+
+bool pinned_release(mifc_ctx* c)
+{
+  hipError_t e = hipEventRecord(c->pinned_read, c->stream);
+  if (e != hipSuccess)
+    return fail(c, "hipEventRecord", e);
+  c->pinned_read_pending = true;
+  return true;
+}
+
+u64* pinned_counts(mifc_ctx* c)
+{
+  return reinterpret_cast<u64*>(c->h_pinned);
+}
+unsigned char* pinned_flags(mifc_ctx* c)
+{
+  return reinterpret_cast<unsigned char*>(c->h_pinned) + 3 * c->cap_lev * sizeof(u64);
+}
+float* pinned_ab(mifc_ctx* c)
+{
+  return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(c->h_pinned) + 3 * c->cap_lev * sizeof(u64) + 2 * c->cap_lev);
+}
+
+// Brings a field to the device if the caller handed a host pointer.
+const float* stage_in(mifc_ctx* c, int s, const float* p, size_t n, int memkind, bool* ok)
+{
+  if (!p || memkind == MIFC_MEM_DEVICE)
+    return p;
+  if (!ensure_slot(c, s, n * sizeof(float))) {
+    *ok = false;
+    return nullptr;
+  }
+  hipError_t e = hipMemcpyAsync(c->slot[s], p, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) {
+    fail(c, "hipMemcpyAsync(H2D)", e);
+    *ok = false;
+    return nullptr;
+  }
+  return static_cast<const float*>(c->slot[s]);
+}
+
+float* stage_out(mifc_ctx* c, int s, float* p, size_t n, int memkind, bool* ok, bool preload = false)
+{
+  if (!p || memkind == MIFC_MEM_DEVICE)
+    return p;
+  if (!ensure_slot(c, s, n * sizeof(float))) {
+    *ok = false;
+    return nullptr;
+  }
+  if (preload) { // operator may leave cells unwritten: start from the caller's content
+    hipError_t e = hipMemcpyAsync(c->slot[s], p, n * sizeof(float), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+      fail(c, "hipMemcpyAsync(H2D)", e);
+      *ok = false;
+      return nullptr;
+    }
+  }
+  return static_cast<float*>(c->slot[s]);
+}
+
+bool fetch_out(mifc_ctx* c, int s, float* p, size_t n, int memkind)
+{
+  if (!p || memkind == MIFC_MEM_DEVICE)
+    return true;
+  hipError_t e = hipMemcpyAsync(p, c->slot[s], n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  if (e != hipSuccess)
+    return fail(c, "hipMemcpyAsync(D2H)", e);
+  return true;
+}
+
+inline bool unit_is(const char* unit, const char* what)
+{
+  return unit && std::strcmp(unit, what) == 0;
+}
+
+// MetConstants.h:43-53 (host copies, evaluated like the reference does on the CPU)
+const float K_CP = 1004.f, K_T0 = 273.15f;
+const float K_P0INV = (float)(1. / 1000.0);
+const float K_KAPPA = 287.f / 1004.f;
+
+inline bool bad_hlevel(float a, float b) // FieldCalculations.cc:298-301
+{
+  return (a < 0.0) || (b < 0.0) || (a == 0.0 && b == 0.0) || (b > 1.0);
+}
+
+// ---- single-field elementwise driver --------------------------------------
+int run_ewise(mifc_ctx* c, mifc::EwiseParams P, const float* in0, const float* in1, const float* in2, float* out, int* fdefined, int memkind,
+              bool may_keep)
+{
+  const size_t n = (size_t)P.n;
+  bool ok = true;
+  P.in0 = stage_in(c, 0, in0, n, memkind, &ok);
+  P.in1 = stage_in(c, 1, in1, n, memkind, &ok);
+  P.in2 = stage_in(c, 2, in2, n, memkind, &ok);
+  P.out = stage_out(c, 3, out, n, memkind, &ok, may_keep);
+  if (!ok || !ensure_levels(c, 1))
+    return 0;
+  P.n_undefined = c->d_counts;
+  if (P.count)
+    MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64), c->stream));
+  MIFC_HIP(c, mifc::launch_ewise(P, c->stream));
+  if (P.count)
+    MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  if (!fetch_out(c, 3, out, n, memkind))
+    return 0;
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  if (P.count)
+    *fdefined = mifc_classify(pinned_counts(c)[0], (u64)n);
+  return 1;
+}
+
+mifc::EwiseParams ewise_base(int op, int nx, int ny, const int* fdefined, float undef)
+{
+  mifc::EwiseParams P;
+  std::memset(&P, 0, sizeof P);
+  P.op = op;
+  P.n = nx * ny;
+  P.all_defined = (*fdefined == MIFC_ALL_DEFINED);
+  P.count = 1;
+  P.undef = undef;
+  P.unit_scale = 100.f;
+  return P;
+}
+
+// ---- single-field / batched stencil driver ---------------------------------
+struct StencilCall
+{
+  int op;
+  int nx, ny, nlev;
+  const float *f0, *f1, *xm, *ym, *fc;
+  float *o0, *o1;
+};
+
+// count range of the raw loop -> what the flag is classified against
+u64 stencil_denominator(int op, int nx, int ny)
+{
+  const u64 n = (u64)nx * (u64)ny;
+  if (op == mifc::ST_IGWIND)
+    return n; // FieldCalculations.cc:1543
+  return n - 2 * (u64)nx; // :1868 and friends, also gradient compute 1 (:2068)
+}
+
+int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, float undef, int memkind)
+{
+  if (sc.nx < 3 || sc.ny < 3 || sc.nlev < 1)
+    return 0;
+  const size_t n = (size_t)sc.nx * sc.ny;
+  const size_t nb = n * (size_t)sc.nlev;
+  bool ok = true;
+  mifc::StencilParams P;
+  std::memset(&P, 0, sizeof P);
+  P.op = sc.op;
+  P.nx = sc.nx;
+  P.ny_global = sc.ny;
+  P.j0 = 0;
+  P.ny_local = sc.ny;
+  P.nlev = sc.nlev;
+  P.f0 = stage_in(c, 0, sc.f0, nb, memkind, &ok);
+  P.f1 = stage_in(c, 1, sc.f1, nb, memkind, &ok);
+  P.xmapr = stage_in(c, 2, sc.xm, n, memkind, &ok);
+  P.ymapr = stage_in(c, 3, sc.ym, n, memkind, &ok);
+  P.fcoriolis = stage_in(c, 4, sc.fc, n, memkind, &ok);
+  P.out0 = stage_out(c, 5, sc.o0, nb, memkind, &ok);
+  P.out1 = stage_out(c, 6, sc.o1, nb, memkind, &ok);
+  if (!ok || !ensure_levels(c, (size_t)sc.nlev))
+    return 0;
+  if (sc.op == mifc::ST_VORTDIV && !P.out0 && P.out1) {
+    // only divergence requested
+    P.op = mifc::ST_DIVERGENCE;
+    P.out0 = P.out1;
+    P.out1 = nullptr;
+  } else if (sc.op == mifc::ST_VORTDIV && !P.out1) {
+    P.op = mifc::ST_RELVORT;
+  }
+  P.in_level_stride = (long)n;
+  P.out_level_stride = (long)n;
+  P.undef = undef;
+  P.n_undefined = c->d_counts;
+  if (!pinned_acquire(c))
+    return 0;
+  bool every_all = true;
+  for (int l = 0; l < sc.nlev; ++l) {
+    const bool a = (fdefined[l] == MIFC_ALL_DEFINED);
+    pinned_flags(c)[l] = a ? 1 : 0;
+    every_all = every_all && a;
+  }
+  P.every_level_all_defined = every_all ? 1 : 0;
+  P.all_defined = c->d_flags;
+  if (!every_all) {
+    MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)sc.nlev, hipMemcpyHostToDevice, c->stream));
+    MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64) * (size_t)sc.nlev, c->stream));
+  }
+  MIFC_HIP(c, mifc::launch_stencil(P, c->stream));
+  if (!every_all)
+    MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64) * (size_t)sc.nlev, hipMemcpyDeviceToHost, c->stream));
+  if (!fetch_out(c, 5, sc.o0, nb, memkind) || !fetch_out(c, 6, sc.o1, nb, memkind))
+    return 0;
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  const u64 denom = stencil_denominator(sc.op, sc.nx, sc.ny);
+  for (int l = 0; l < sc.nlev; ++l) {
+    if (sc.op == mifc::ST_GWIND_X)
+      fdefined[l] = mifc_classify(denom, denom); // FieldCalculations.cc:664: every cell is counted
+    else
+      fdefined[l] = every_all ? MIFC_ALL_DEFINED : mifc_classify(pinned_counts(c)[l], denom);
+  }
+  return 1;
+}
+
+} // namespace
+
+extern "C" {
+
+int mifc_abi_version(void)
+{
+  return MIFC_ABI_VERSION;
+}
+
+int mifc_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+mifc_ctx* mifc_create(int device)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n)
+    return nullptr;
+  if (hipSetDevice(device) != hipSuccess)
+    return nullptr;
+  mifc_ctx* c = new (std::nothrow) mifc_ctx();
+  if (!c)
+    return nullptr;
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  c->stream = c->own_stream;
+  if (hipEventCreateWithFlags(&c->pinned_read, hipEventDisableTiming) != hipSuccess) {
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+void mifc_destroy(mifc_ctx* c)
+{
+  if (!c)
+    return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (int s = 0; s < mifc_ctx::NSLOT; ++s)
+    if (c->slot[s])
+      (void)hipFree(c->slot[s]);
+  if (c->d_flags)
+    (void)hipFree(c->d_flags);
+  if (c->d_counts)
+    (void)hipFree(c->d_counts);
+  if (c->d_ab)
+    (void)hipFree(c->d_ab);
+  if (c->h_pinned)
+    (void)hipHostFree(c->h_pinned);
+  if (c->pinned_read)
+    (void)hipEventDestroy(c->pinned_read);
+  if (c->own_stream)
+    (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* mifc_last_error(const mifc_ctx* c)
+{
+  return c ? c->err.c_str() : "no context (no usable HIP device)";
+}
+
+int mifc_set_stream(mifc_ctx* c, void* hip_stream)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return 1;
+}
+
+int mifc_synchronize(mifc_ctx* c)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  return 1;
+}
+
+void* mifc_device_alloc(mifc_ctx* c, size_t bytes)
+{
+  if (!c)
+    return nullptr;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    fail(c, "hipMalloc", e);
+    return nullptr;
+  }
+  return p;
+}
+
+int mifc_device_free(mifc_ctx* c, void* dptr)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  MIFC_HIP(c, hipFree(dptr));
+  return 1;
+}
+
+int mifc_copy_to_device(mifc_ctx* c, void* dst_dev, const void* src_host, size_t bytes)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  MIFC_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  return 1;
+}
+
+int mifc_copy_to_host(mifc_ctx* c, void* dst_host, const void* src_dev, size_t bytes)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  MIFC_HIP(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  return 1;
+}
+
+int mifc_classify(unsigned long long n_undefined, unsigned long long n)
+{
+  if (n_undefined == 0)
+    return MIFC_ALL_DEFINED;
+  if (n_undefined == n)
+    return MIFC_NONE_DEFINED;
+  return MIFC_SOME_DEFINED;
+}
+
+// ------------------------------------------------------------- elementwise
+
+int mifc_vectorabs(mifc_ctx* c, int nx, int ny, const float* u, const float* v, float* ff, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (nx * ny <= 0) { // empty loop, checkDefined(0, 0)
+    *fdefined = MIFC_ALL_DEFINED;
+    return 1;
+  }
+  mifc::EwiseParams P = ewise_base(mifc::EW_VECTORABS, nx, ny, fdefined, undef);
+  return run_ewise(c, P, u, v, nullptr, ff, fdefined, memkind, false);
+}
+
+int mifc_pleveltemp(mifc_ctx* c, int nx, int ny, const float* tinp, float p, const char* unit, int compute, float* tout, int* fdefined, float undef,
+                    int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (p <= 0) // FieldCalculations.cc:330
+    return 0;
+  if (compute < 3) { // :340-345
+    if (unit_is(unit, "celsius"))
+      compute = 1;
+    else if (unit_is(unit, "kelvin"))
+      compute = 2;
+  }
+  if (compute < 1 || compute > 5) // :364
+    return 0;
+  mifc::EwiseParams P = ewise_base(mifc::EW_TEMP, nx, ny, fdefined, undef);
+  P.psrc = mifc::PS_SCALAR;
+  P.compute = compute;
+  P.p = p;
+  P.pidcp = powf(p * K_P0INV, K_KAPPA); // :347, on the host like the reference
+  P.pi = P.pidcp * K_CP;
+  P.count = (compute >= 4); // compute 1..3 leave fDefined untouched (:94-122)
+  if (P.n <= 0) {
+    if (P.count)
+      *fdefined = MIFC_ALL_DEFINED;
+    return 1;
+  }
+  return run_ewise(c, P, tinp, nullptr, nullptr, tout, fdefined, memkind, false);
+}
+
+int mifc_hleveltemp(mifc_ctx* c, int nx, int ny, const float* tinp, const float* ps, float alevel, float blevel, const char* unit, int compute,
+                    float* tout, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (compute < 3) { // :1060-1065
+    if (unit_is(unit, "celsius"))
+      compute = 1;
+    else if (unit_is(unit, "kelvin"))
+      compute = 2;
+  }
+  if (bad_hlevel(alevel, blevel)) // :1070
+    return 0;
+  mifc::EwiseParams P = ewise_base(mifc::EW_TEMP, nx, ny, fdefined, undef);
+  P.psrc = mifc::PS_HYBRID;
+  P.compute = compute; // no range check in the reference: other values leave defined cells unwritten
+  P.alevel = alevel;
+  P.blevel = blevel;
+  if (P.n <= 0) {
+    *fdefined = MIFC_ALL_DEFINED; // checkDefined(0, 0)
+    return 1;
+  }
+  return run_ewise(c, P, tinp, nullptr, ps, tout, fdefined, memkind, compute < 1 || compute > 5);
+}
+
+int mifc_aleveltemp(mifc_ctx* c, int nx, int ny, const float* tinp, const float* p, const char* unit, int compute, float* tout, int* fdefined,
+                    float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (compute <= 0 || compute >= 6) // :1319
+    return 0;
+  if (compute < 3) {
+    if (unit_is(unit, "celsius"))
+      compute = 1;
+    else if (unit_is(unit, "kelvin"))
+      compute = 2;
+  }
+  mifc::EwiseParams P = ewise_base(mifc::EW_TEMP, nx, ny, fdefined, undef);
+  P.psrc = mifc::PS_FIELD;
+  P.compute = compute;
+  if (P.n <= 0) {
+    *fdefined = MIFC_ALL_DEFINED;
+    return 1;
+  }
+  return run_ewise(c, P, tinp, nullptr, p, tout, fdefined, memkind, false);
+}
+
+static int hum_kind_ah(int compute) // numbering of alevelhum / hlevelhum (:1157-1164)
+{
+  if (compute <= 2)
+    return mifc::HUM_Q_RH;
+  if (compute <= 4)
+    return mifc::HUM_RH_Q;
+  if (compute == 5 || compute == 6 || compute == 9 || compute == 10)
+    return mifc::HUM_Q_TD;
+  return mifc::HUM_RH_TD;
+}
+
+int mifc_plevelhum(mifc_ctx* c, int nx, int ny, const float* t, const float* huminp, float p, const char* unit, int compute, float* humout,
+                   int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (p <= 0 || compute <= 0 || compute >= 13) // :419
+    return 0;
+  if (compute > 8 && unit_is(unit, "celsius")) // :422-425
+    compute -= 4;
+  else if (compute > 4 && compute <= 8 && unit_is(unit, "kelvin"))
+    compute += 4;
+  const int n = nx * ny;
+  const bool rh_td = (compute == 5 || compute == 6 || compute == 9 || compute == 10);
+  mifc::EwiseParams P = ewise_base(mifc::EW_HUM, nx, ny, fdefined, undef);
+  P.psrc = mifc::PS_SCALAR;
+  P.p = p;
+  if (p == undef && !rh_td) { // :429-432 fillUndef (:76-82): result undef everywhere, NONE_DEFINED
+    if (n > 0) {
+      bool ok = true;
+      float* out = stage_out(c, 3, humout, (size_t)n, memkind, &ok);
+      if (!ok)
+        return 0;
+      unsigned int bits;
+      std::memcpy(&bits, &undef, sizeof bits);
+      MIFC_HIP(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out), (int)bits, (size_t)n, c->stream));
+      if (!fetch_out(c, 3, humout, (size_t)n, memkind))
+        return 0;
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    *fdefined = MIFC_NONE_DEFINED;
+    return 1;
+  }
+  const float pi = K_CP * powf(p * K_P0INV, K_KAPPA); // :434 pi_from_p, on the host
+  P.pi = pi;
+  P.tconv = (compute % 2 == 0) ? (pi / K_CP) : 1; // :436
+  P.tdconv = (compute >= 9) ? K_T0 : 0;           // :437
+  if (compute <= 2) // numbering of plevelhum (:408-415)
+    P.kind = mifc::HUM_Q_RH;
+  else if (compute <= 4)
+    P.kind = mifc::HUM_RH_Q;
+  else if (rh_td)
+    P.kind = mifc::HUM_RH_TD;
+  else
+    P.kind = mifc::HUM_Q_TD;
+  P.ptest = mifc::PT_NONE;
+  if (n <= 0) {
+    *fdefined = MIFC_ALL_DEFINED;
+    return 1;
+  }
+  return run_ewise(c, P, t, huminp, nullptr, humout, fdefined, memkind, false);
+}
+
+int mifc_hlevelhum(mifc_ctx* c, int nx, int ny, const float* t, const float* huminp, const float* ps, float alevel, float blevel, const char* unit,
+                   int compute, float* humout, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (compute <= 0 || compute >= 13) // :1168
+    return 0;
+  if (bad_hlevel(alevel, blevel)) // :1170
+    return 0;
+  if (compute > 8 && unit_is(unit, "celsius")) // :1174-1177
+    compute -= 4;
+  else if (compute > 4 && compute <= 8 && unit_is(unit, "kelvin"))
+    compute += 4;
+  mifc::EwiseParams P = ewise_base(mifc::EW_HUM, nx, ny, fdefined, undef);
+  P.psrc = mifc::PS_HYBRID;
+  P.alevel = alevel;
+  P.blevel = blevel;
+  P.tdconv = (compute >= 9) ? K_T0 : 0; // :1181
+  P.kind = hum_kind_ah(compute);
+  P.from_theta = (compute % 2 == 0);
+  const bool need_p = !(compute == 7 || compute == 11); // :1182
+  P.ptest = need_p ? mifc::PT_NEQ : mifc::PT_NONE;
+  if (P.n <= 0) {
+    *fdefined = MIFC_ALL_DEFINED;
+    return 1;
+  }
+  return run_ewise(c, P, t, huminp, need_p ? ps : nullptr, humout, fdefined, memkind, false);
+}
+
+int mifc_alevelhum(mifc_ctx* c, int nx, int ny, const float* t, const float* huminp, const float* p, const char* unit, int compute, float* humout,
+                   int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (compute <= 0 || compute >= 13) // :1414
+    return 0;
+  if (compute > 8 && unit_is(unit, "celsius")) // :1417-1420
+    compute -= 4;
+  else if (compute > 4 && compute <= 8 && unit_is(unit, "kelvin"))
+    compute += 4;
+  mifc::EwiseParams P = ewise_base(mifc::EW_HUM, nx, ny, fdefined, undef);
+  P.psrc = mifc::PS_FIELD;
+  P.tdconv = (compute >= 9) ? K_T0 : 0; // :1423
+  P.kind = hum_kind_ah(compute);
+  P.from_theta = (compute % 2 == 0);
+  // :1429 -- p is tested (with != undef) only for compute 7/11, which do not use it
+  const bool tests_p = (compute == 7 || compute == 11);
+  P.ptest = tests_p ? mifc::PT_NEQ : mifc::PT_NONE;
+  const bool reads_p = !tests_p || !P.all_defined;
+  if (P.n <= 0) {
+    *fdefined = MIFC_ALL_DEFINED;
+    return 1;
+  }
+  return run_ewise(c, P, t, huminp, reads_p ? p : nullptr, humout, fdefined, memkind, false);
+}
+
+int mifc_cvhum(mifc_ctx* c, int nx, int ny, const float* t, const float* huminp, const char* unit, int compute, float* humout, int* fdefined,
+               float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  float unit_scale = 100; // :1746-1750
+  if (compute == 1 && unit_is(unit, "celsius"))
+    compute = 2;
+  if ((compute == 4 || compute == 5) && unit_is(unit, "1"))
+    unit_scale = 1;
+  if (compute < 1 || compute > 5) // :1813
+    return 0;
+  mifc::EwiseParams P = ewise_base(compute <= 3 ? mifc::EW_CVHUM_TD : mifc::EW_CVHUM_RH, nx, ny, fdefined, undef);
+  P.tconv = (compute == 1 || compute == 2 || compute == 4) ? K_T0 : 0; // :1753
+  P.tdconv = (compute == 1) ? K_T0 : 0;                                 // :1754
+  P.unit_scale = unit_scale;
+  if (P.n <= 0) {
+    *fdefined = MIFC_ALL_DEFINED;
+    return 1;
+  }
+  return run_ewise(c, P, t, huminp, nullptr, humout, fdefined, memkind, false);
+}
+
+// ---------------------------------------------------------------- stencils
+
+int mifc_relvort(mifc_ctx* c, int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr, float* rvort, int* fdefined,
+                 float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  const StencilCall sc = {mifc::ST_RELVORT, nx, ny, 1, u, v, xmapr, ymapr, nullptr, rvort, nullptr};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+int mifc_absvort(mifc_ctx* c, int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr, const float* fcoriolis,
+                 float* avort, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  const StencilCall sc = {mifc::ST_ABSVORT, nx, ny, 1, u, v, xmapr, ymapr, fcoriolis, avort, nullptr};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+int mifc_divergence(mifc_ctx* c, int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr, float* diverg,
+                    int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  const StencilCall sc = {mifc::ST_DIVERGENCE, nx, ny, 1, u, v, xmapr, ymapr, nullptr, diverg, nullptr};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+int mifc_gradient(mifc_ctx* c, int nx, int ny, const float* field, const float* xmapr, const float* ymapr, int compute, float* fgrad, int* fdefined,
+                  float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (compute < 1 || compute > 4) // :2064 (size check comes first in the reference, both return false)
+    return 0;
+  const int op = mifc::ST_GRAD_X + (compute - 1);
+  const StencilCall sc = {op, nx, ny, 1, field, nullptr, xmapr, ymapr, nullptr, fgrad, nullptr};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+int mifc_plevelgwind_xcomp(mifc_ctx* c, int nx, int ny, const float* z, const float* xmapr, const float* ymapr, const float* fcoriolis, float* ug,
+                           int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  (void)xmapr; // unused by the reference as well (:638)
+  const StencilCall sc = {mifc::ST_GWIND_X, nx, ny, 1, z, nullptr, nullptr, ymapr, fcoriolis, ug, nullptr};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+int mifc_plevelgwind_ycomp(mifc_ctx* c, int nx, int ny, const float* z, const float* xmapr, const float* ymapr, const float* fcoriolis, float* vg,
+                           int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  (void)ymapr;
+  // the reference lacks the nx<3||ny<3 guard here and would read out of bounds;
+  // this implementation returns false instead
+  const StencilCall sc = {mifc::ST_GWIND_Y, nx, ny, 1, z, nullptr, xmapr, nullptr, fcoriolis, vg, nullptr};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+int mifc_plevelgvort(mifc_ctx* c, int nx, int ny, const float* z, const float* xmapr, const float* ymapr, const float* fcoriolis, float* gvort,
+                     int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  const StencilCall sc = {mifc::ST_GVORT, nx, ny, 1, z, nullptr, xmapr, ymapr, fcoriolis, gvort, nullptr};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+int mifc_ilevelgwind(mifc_ctx* c, int nx, int ny, const float* mpot, const float* xmapr, const float* ymapr, const float* fcoriolis, float* ug,
+                     float* vg, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  const StencilCall sc = {mifc::ST_IGWIND, nx, ny, 1, mpot, nullptr, xmapr, ymapr, fcoriolis, ug, vg};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+// ----------------------------------------------------------------- batched
+
+int mifc_vortdiv_levels(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr, float* rvort,
+                        float* diverg, int* fdefined, float undef, int memkind)
+{
+  if (!c || (!rvort && !diverg))
+    return 0;
+  c->err.clear();
+  const StencilCall sc = {mifc::ST_VORTDIV, nx, ny, nlev, u, v, xmapr, ymapr, nullptr, rvort, diverg};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
+                                float* rvort, float* diverg, const int* fdefined_in, float undef, unsigned long long* n_undefined_dev)
+{
+  if (!c || (!rvort && !diverg))
+    return 0;
+  c->err.clear();
+  if (nx < 3 || ny < 3 || nlev < 1)
+    return 0;
+  if (!ensure_levels(c, (size_t)nlev))
+    return 0;
+  mifc::StencilParams P;
+  std::memset(&P, 0, sizeof P);
+  P.op = mifc::ST_VORTDIV;
+  P.out0 = rvort;
+  P.out1 = diverg;
+  if (!rvort) {
+    P.op = mifc::ST_DIVERGENCE;
+    P.out0 = diverg;
+    P.out1 = nullptr;
+  } else if (!diverg) {
+    P.op = mifc::ST_RELVORT;
+  }
+  P.nx = nx;
+  P.ny_global = ny;
+  P.j0 = 0;
+  P.ny_local = ny;
+  P.nlev = nlev;
+  P.f0 = u;
+  P.f1 = v;
+  P.xmapr = xmapr;
+  P.ymapr = ymapr;
+  P.in_level_stride = (long)nx * ny;
+  P.out_level_stride = (long)nx * ny;
+  P.undef = undef;
+  if (!pinned_acquire(c))
+    return 0;
+  bool every_all = (fdefined_in != nullptr);
+  for (int l = 0; l < nlev; ++l) {
+    const bool a = fdefined_in && fdefined_in[l] == MIFC_ALL_DEFINED;
+    pinned_flags(c)[l] = a ? 1 : 0;
+    every_all = every_all && a;
+  }
+  P.every_level_all_defined = every_all ? 1 : 0;
+  P.all_defined = c->d_flags;
+  P.n_undefined = n_undefined_dev;
+  if (!every_all) {
+    if (!n_undefined_dev) {
+      c->err = "mifc_vortdiv_levels_enqueue: n_undefined_dev is required unless every level is ALL_DEFINED";
+      return 0;
+    }
+    MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)nlev, hipMemcpyHostToDevice, c->stream));
+    if (!pinned_release(c))
+      return 0;
+  }
+  if (n_undefined_dev)
+    MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64) * (size_t)nlev, c->stream));
+  MIFC_HIP(c, mifc::launch_stencil(P, c->stream));
+  return 1;
+}
+
+static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q, const float* ps,
+                          const float* alevel, const float* blevel, float* ff, float* rh, float* theta, const int* fdef_wind, const int* fdef_thermo,
+                          float undef, u64* counts_dev, bool* every_all_out)
+{
+  if (nlev < 1 || nx * ny <= 0)
+    return 0;
+  if (!ff && !rh && !theta)
+    return 0;
+  if (rh || theta) {
+    for (int l = 0; l < nlev; ++l)
+      if (bad_hlevel(alevel[l], blevel[l])) // :1070, :1170
+        return 0;
+  }
+  if (!ensure_levels(c, (size_t)nlev))
+    return 0;
+  mifc::DerivedParams P;
+  std::memset(&P, 0, sizeof P);
+  P.n = nx * ny;
+  P.nlev = nlev;
+  P.u = u;
+  P.v = v;
+  P.t = t;
+  P.q = q;
+  P.ps = ps;
+  P.ff = ff;
+  P.rh = rh;
+  P.theta = theta;
+  P.undef = undef;
+  if (!pinned_acquire(c))
+    return 0;
+  bool every_all = true;
+  unsigned char* hf = pinned_flags(c);
+  for (int l = 0; l < nlev; ++l) {
+    const bool w = !ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
+    const bool th = !(rh || theta) || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
+    hf[l] = w ? 1 : 0;
+    hf[c->cap_lev + l] = th ? 1 : 0;
+    every_all = every_all && w && th;
+  }
+  float* hab = pinned_ab(c);
+  for (int l = 0; l < nlev; ++l) {
+    hab[l] = (rh || theta) ? alevel[l] : 0.f;
+    hab[c->cap_lev + l] = (rh || theta) ? blevel[l] : 0.f;
+  }
+  MIFC_HIP(c, hipMemcpyAsync(c->d_ab, hab, 2 * c->cap_lev * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  MIFC_HIP(c, hipMemcpyAsync(c->d_flags, hf, 2 * c->cap_lev, hipMemcpyHostToDevice, c->stream));
+  if (!pinned_release(c))
+    return 0;
+  P.alevel = c->d_ab;
+  P.blevel = c->d_ab + c->cap_lev;
+  P.wind_all_defined = c->d_flags;
+  P.thermo_all_defined = c->d_flags + c->cap_lev;
+  P.every_level_all_defined = every_all ? 1 : 0;
+  P.n_undefined = counts_dev;
+  MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 3 * sizeof(u64) * (size_t)nlev, c->stream));
+  MIFC_HIP(c, mifc::launch_derived_levels(P, c->stream));
+  if (every_all_out)
+    *every_all_out = every_all;
+  return 1;
+}
+
+int mifc_hlevel_derived_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q,
+                                       const float* ps, const float* alevel, const float* blevel, float* ff, float* rh, float* theta,
+                                       const int* fdef_wind, const int* fdef_thermo, float undef, unsigned long long* n_undefined_dev)
+{
+  if (!c || !n_undefined_dev)
+    return 0;
+  c->err.clear();
+  if ((nx * ny) % 4 != 0) {
+    c->err = "mifc_hlevel_derived_levels: nx*ny must be a multiple of 4 (use the per-field operators otherwise)";
+    return 0;
+  }
+  return derived_common(c, nx, ny, nlev, u, v, t, q, ps, alevel, blevel, ff, rh, theta, fdef_wind, fdef_thermo, undef, n_undefined_dev, nullptr);
+}
+
+int mifc_hlevel_derived_levels(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q, const float* ps,
+                               const float* alevel, const float* blevel, float* ff, float* rh, float* theta, const int* fdef_wind,
+                               const int* fdef_thermo, int* fdef_ff, int* fdef_rh, int* fdef_theta, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (nlev < 1 || nx * ny <= 0)
+    return 0;
+  if ((nx * ny) % 4 != 0) {
+    c->err = "mifc_hlevel_derived_levels: nx*ny must be a multiple of 4 (use the per-field operators otherwise)";
+    return 0;
+  }
+  const size_t n = (size_t)nx * ny, nb = n * (size_t)nlev;
+  bool ok = true;
+  const float* du = ff ? stage_in(c, 0, u, nb, memkind, &ok) : nullptr;
+  const float* dv = ff ? stage_in(c, 1, v, nb, memkind, &ok) : nullptr;
+  const float* dt = (rh || theta) ? stage_in(c, 2, t, nb, memkind, &ok) : nullptr;
+  const float* dq = rh ? stage_in(c, 3, q, nb, memkind, &ok) : nullptr;
+  const float* dps = (rh || theta) ? stage_in(c, 4, ps, n, memkind, &ok) : nullptr;
+  float* dff = stage_out(c, 5, ff, nb, memkind, &ok);
+  float* drh = stage_out(c, 6, rh, nb, memkind, &ok);
+  float* dth = stage_out(c, 7, theta, nb, memkind, &ok);
+  if (!ok || !ensure_levels(c, (size_t)nlev))
+    return 0;
+  if (!derived_common(c, nx, ny, nlev, du, dv, dt, dq, dps, alevel, blevel, dff, drh, dth, fdef_wind, fdef_thermo, undef, c->d_counts, nullptr))
+    return 0;
+  MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, 3 * sizeof(u64) * (size_t)nlev, hipMemcpyDeviceToHost, c->stream));
+  if (!fetch_out(c, 5, ff, nb, memkind) || !fetch_out(c, 6, rh, nb, memkind) || !fetch_out(c, 7, theta, nb, memkind))
+    return 0;
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  const u64* cnt = pinned_counts(c);
+  for (int l = 0; l < nlev; ++l) {
+    if (ff && fdef_ff)
+      fdef_ff[l] = mifc_classify(cnt[l], (u64)n);
+    if (rh && fdef_rh)
+      fdef_rh[l] = mifc_classify(cnt[nlev + l], (u64)n);
+    if (theta && fdef_theta)
+      fdef_theta[l] = mifc_classify(cnt[2 * nlev + l], (u64)n);
+  }
+  return 1;
+}
+
+int mifc_vortdiv_slab_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny_local, const float* u_halo, const float* v_halo, const float* xmapr,
+                              const float* ymapr, float* rvort, float* diverg, int fdefined_in, float undef, unsigned long long* n_undefined_dev)
+{
+  if (!c || (!rvort && !diverg))
+    return 0;
+  c->err.clear();
+  if (nx < 3 || ny_global < 3 || ny_local < 1 || j0 < 0 || j0 + ny_local > ny_global)
+    return 0;
+  // a slab that owns a global edge row must also own the row it is filled from
+  if ((j0 == 0 || j0 + ny_local == ny_global) && ny_local < 2)
+    return 0;
+  mifc::StencilParams P;
+  std::memset(&P, 0, sizeof P);
+  P.op = mifc::ST_VORTDIV;
+  P.out0 = rvort;
+  P.out1 = diverg;
+  if (!rvort) {
+    P.op = mifc::ST_DIVERGENCE;
+    P.out0 = diverg;
+    P.out1 = nullptr;
+  } else if (!diverg) {
+    P.op = mifc::ST_RELVORT;
+  }
+  P.nx = nx;
+  P.ny_global = ny_global;
+  P.j0 = j0;
+  P.ny_local = ny_local;
+  P.nlev = 1;
+  P.f0 = u_halo + nx; // owned row 0; halo rows sit directly before and after
+  P.f1 = v_halo + nx;
+  P.xmapr = xmapr;
+  P.ymapr = ymapr;
+  P.undef = undef;
+  P.every_level_all_defined = (fdefined_in == MIFC_ALL_DEFINED) ? 1 : 0;
+  P.all_defined = nullptr;
+  P.n_undefined = n_undefined_dev;
+  if (!P.every_level_all_defined && !n_undefined_dev) {
+    c->err = "mifc_vortdiv_slab_enqueue: n_undefined_dev is required unless the input is ALL_DEFINED";
+    return 0;
+  }
+  if (n_undefined_dev)
+    MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64), c->stream));
+  MIFC_HIP(c, mifc::launch_stencil(P, c->stream));
+  return 1;
+}
+
+} // extern "C"

@@ -1,0 +1,342 @@
+// mifc_ewise.hip -- elementwise derived-variable kernels for gfx950.
+//
+// One pass over the field(s): 16-byte coalesced loads (4 cells per lane),
+// point function per cell, 16-byte stores, per-wave undefined count -> one
+// atomic per wave.  All of these operators are HBM-bound (8..32 B per cell);
+// the only non-trivial ALU work is powf (theta) and the saturation-pressure
+// table walk (dew point), both far under the vector-ALU roof at HBM speed.
+#include "mifc_device.h"
+#include "mifc_kernels.h"
+
+namespace mifc {
+
+namespace {
+
+// Point function of the single-field operators.  Returns true when the cell is
+// defined (r holds the value); false => cell := undef and is counted.
+// `keep` is set for the one case where the reference leaves a defined cell
+// unwritten (hleveltemp with compute outside 1..5, FieldCalculations.cc:1080-1090).
+__device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* tab, float a, float b, float c, float& r, bool& keep)
+{
+  const bool all = P.all_defined != 0;
+  const float undef = P.undef;
+  keep = false;
+  switch (P.op) {
+  case EW_VECTORABS: { // :1831-1837
+    if (!(all || (is_def(a, undef) && is_def(b, undef))))
+      return false;
+    r = absval(a, b);
+    return true;
+  }
+  case EW_TEMP: {
+    float p, pidcp, pi;
+    if (P.psrc == PS_SCALAR) { // pleveltemp :347-363 (p hoisted, evaluated on the host)
+      if (!(all || is_def(a, undef)))
+        return false;
+      p = P.p;
+      pidcp = P.pidcp;
+      pi = P.pi;
+    } else {
+      if (!(all || (is_def(a, undef) && is_def(c, undef)))) // :1077, :1334
+        return false;
+      p = (P.psrc == PS_HYBRID) ? (P.alevel + P.blevel * c) : c; // :303
+      pidcp = pidcp_of(p);
+      pi = pidcp * MIFC_K_CP;
+    }
+    switch (P.compute) {
+    case 1:
+      r = a * pidcp - MIFC_K_T0;
+      return true;
+    case 2:
+      r = a * pidcp;
+      return true;
+    case 3:
+      r = a / pidcp;
+      return true;
+    case 4:
+      return t_thesat(tab, a, p, pi, r);
+    case 5:
+      return th_thesat(tab, a, p, pi, r);
+    default:
+      keep = true;
+      return true;
+    }
+  }
+  case EW_HUM: {
+    bool ok = all || (is_def(a, undef) && is_def(b, undef)); // :443, :1187, :1429
+    if (P.ptest == PT_NEQ)
+      ok = ok && (all || c != undef);
+    if (!ok)
+      return false;
+    float p, tk;
+    if (P.psrc == PS_SCALAR) { // plevelhum :434-456
+      p = P.p;
+      tk = a * P.tconv;
+    } else {
+      if (P.psrc == PS_HYBRID)
+        p = (P.kind == HUM_RH_TD && !P.from_theta) ? 0.0f : (P.alevel + P.blevel * c); // need_p :1182,:1188
+      else
+        p = c;
+      tk = P.from_theta ? a * pidcp_of(p) : a;
+    }
+    switch (P.kind) {
+    case HUM_Q_RH:
+      return tk_q_rh(tab, tk, b, p, r);
+    case HUM_RH_Q:
+      return tk_rh_q(tab, tk, b, p, r);
+    case HUM_Q_TD:
+      return tk_q_td(tab, tk, b, p, P.tdconv, r);
+    default:
+      return tk_rh_td(tab, tk, b, P.tdconv, r);
+    }
+  }
+  case EW_CVHUM_TD: { // :1765-1782
+    if (!(all || (is_def(a, undef) && is_def(b, undef))))
+      return false;
+    const Ewt e(a - P.tconv);
+    if (!e.ok())
+      return false;
+    const float et = e.value(tab);
+    const float rh = clamp_rh((float)(0.01 * (double)b));
+    r = e.inverse(tab, rh * et) + P.tdconv;
+    return true;
+  }
+  default: { // EW_CVHUM_RH :1792-1808
+    if (!(all || (is_def(a, undef) && is_def(b, undef))))
+      return false;
+    const Ewt e(a - P.tconv), e2(b - P.tconv);
+    if (!(e.ok() && e2.ok()))
+      return false;
+    const float rh = e2.value(tab) / e.value(tab);
+    r = rh * P.unit_scale;
+    return true;
+  }
+  }
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
+{
+  __shared__ float s_ewt[MIFC_N_EWT];
+  ewt_table_init(s_ewt);
+
+  const bool use1 = P.in1 != nullptr;
+  const bool use2 = P.in2 != nullptr;
+  const bool may_keep = (P.op == EW_TEMP) && (P.compute < 1 || P.compute > 5);
+  unsigned int bad = 0;
+
+  if (VEC4) {
+    const int n4 = P.n >> 2;
+    const float4* __restrict__ a4p = reinterpret_cast<const float4*>(P.in0);
+    const float4* __restrict__ b4p = reinterpret_cast<const float4*>(P.in1);
+    const float4* __restrict__ c4p = reinterpret_cast<const float4*>(P.in2);
+    float4* o4p = reinterpret_cast<float4*>(P.out);
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += gridDim.x * blockDim.x) {
+      const float4 a4 = a4p[q];
+      const float4 b4 = use1 ? b4p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 c4 = use2 ? c4p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 o4 = may_keep ? o4p[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+      const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+      const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+      float ov[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float r = 0.f;
+        bool keep;
+        if (ewise_point(P, s_ewt, av[k], bv[k], cv[k], r, keep)) {
+          if (!keep)
+            ov[k] = r;
+        } else {
+          ov[k] = P.undef;
+          bad += 1;
+        }
+      }
+      o4p[q] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+    }
+    // tail cells (n not a multiple of 4) are handled by a second, scalar launch
+  } else {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x) {
+      const float a = P.in0[i];
+      const float b = use1 ? P.in1[i] : 0.f;
+      const float c = use2 ? P.in2[i] : 0.f;
+      float r = 0.f;
+      bool keep;
+      if (ewise_point(P, s_ewt, a, b, c, r, keep)) {
+        if (!keep)
+          P.out[i] = r;
+      } else {
+        P.out[i] = P.undef;
+        bad += 1;
+      }
+    }
+  }
+  if (P.count)
+    wave_count_add(P.n_undefined, bad);
+}
+
+inline bool aligned16(const void* p)
+{
+  return (reinterpret_cast<size_t>(p) & 15u) == 0;
+}
+
+inline int grid_for(int work_items, int block, int max_blocks)
+{
+  int g = (work_items + block - 1) / block;
+  if (g < 1)
+    g = 1;
+  return g > max_blocks ? max_blocks : g;
+}
+
+} // namespace
+
+hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
+{
+  if (prm.n <= 0)
+    return hipSuccess;
+  const bool vec_ok = aligned16(prm.in0) && aligned16(prm.out) && (!prm.in1 || aligned16(prm.in1)) && (!prm.in2 || aligned16(prm.in2)) && prm.n >= 4;
+  const int block = 256;
+  if (vec_ok) {
+    const int n4 = prm.n >> 2;
+    hipLaunchKernelGGL(ewise_kernel<true>, dim3(grid_for(n4, block, 256 * 16)), dim3(block), 0, stream, prm);
+    const int tail = prm.n - n4 * 4;
+    if (tail > 0) {
+      EwiseParams t = prm;
+      t.n = tail;
+      t.in0 = prm.in0 + n4 * 4;
+      t.in1 = prm.in1 ? prm.in1 + n4 * 4 : nullptr;
+      t.in2 = prm.in2 ? prm.in2 + n4 * 4 : nullptr;
+      t.out = prm.out + n4 * 4;
+      hipLaunchKernelGGL(ewise_kernel<false>, dim3(1), dim3(64), 0, stream, t);
+    }
+  } else {
+    hipLaunchKernelGGL(ewise_kernel<false>, dim3(grid_for(prm.n, block, 256 * 16)), dim3(block), 0, stream, prm);
+  }
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------
+// Fused (ff, rh, theta) over hybrid model levels -- BASELINE.json config 2.
+//   ff    = vectorabs(u,v)                      12 B/cell alone
+//   rh    = hlevelhum compute 1  (T,q,ps -> RH %)
+//   theta = hleveltemp compute 3 (T,ps -> theta)
+// Fused traffic: u,v,t,q read once (16 B), ps re-read per level from L2/MALL,
+// three outputs (12 B)  => 28 B/cell + ps.  p = a + b*ps and powf(p*p0inv,
+// kappa) are evaluated once per cell and shared by rh (needs p) and theta
+// (needs pidcp).  grid.y = level; each lane owns 4 consecutive cells.
+template <bool CHECK>
+__global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams P)
+{
+  __shared__ float s_ewt[MIFC_N_EWT];
+  ewt_table_init(s_ewt);
+
+  const int lev = blockIdx.y;
+  const size_t base = (size_t)lev * (size_t)P.n;
+  const bool want_ff = P.ff != nullptr, want_rh = P.rh != nullptr, want_th = P.theta != nullptr;
+  const bool wind_all = CHECK ? (P.wind_all_defined[lev] != 0) : true;
+  const bool thermo_all = CHECK ? (P.thermo_all_defined[lev] != 0) : true;
+  const float a = P.alevel[lev], b = P.blevel[lev];
+  const float undef = P.undef;
+  unsigned int bad_ff = 0, bad_rh = 0, bad_th = 0;
+
+  const int n4 = P.n >> 2;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += gridDim.x * blockDim.x) {
+    const size_t o = base + (size_t)q * 4;
+    if (want_ff) {
+      const float4 u4 = *reinterpret_cast<const float4*>(P.u + o);
+      const float4 v4 = *reinterpret_cast<const float4*>(P.v + o);
+      const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+      float r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (wind_all || (is_def(uu[k], undef) && is_def(vv[k], undef))) {
+          r[k] = absval(uu[k], vv[k]);
+        } else {
+          r[k] = undef;
+          bad_ff += 1;
+        }
+      }
+      *reinterpret_cast<float4*>(P.ff + o) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+    if (want_rh || want_th) {
+      const float4 t4 = *reinterpret_cast<const float4*>(P.t + o);
+      const float4 s4 = *reinterpret_cast<const float4*>(P.ps + (size_t)q * 4);
+      const float4 q4 = want_rh ? *reinterpret_cast<const float4*>(P.q + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float tt[4] = {t4.x, t4.y, t4.z, t4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
+      float rr[4], rt[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float p = a + b * ss[k]; // p_hlevel :303
+        if (want_th) {              // hleveltemp compute 3, :1077-1085
+          if (thermo_all || (is_def(tt[k], undef) && is_def(ss[k], undef))) {
+            rt[k] = tt[k] / pidcp_of(p);
+          } else {
+            rt[k] = undef;
+            bad_th += 1;
+          }
+        }
+        if (want_rh) { // hlevelhum compute 1, :1187-1190 (ps tested with != undef only)
+          float r;
+          if ((thermo_all || (is_def(tt[k], undef) && is_def(qq[k], undef) && ss[k] != undef)) && tk_q_rh(s_ewt, tt[k], qq[k], p, r)) {
+            rr[k] = r;
+          } else {
+            rr[k] = undef;
+            bad_rh += 1;
+          }
+        }
+      }
+      if (want_rh)
+        *reinterpret_cast<float4*>(P.rh + o) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+      if (want_th)
+        *reinterpret_cast<float4*>(P.theta + o) = make_float4(rt[0], rt[1], rt[2], rt[3]);
+    }
+  }
+  // The ewt table can reject a cell even when the inputs are ALL_DEFINED, so
+  // rh is always counted; ff / theta only need counting when tests ran.
+  if (P.n_undefined) {
+    if (CHECK && want_ff)
+      wave_count_add(P.n_undefined + lev, bad_ff);
+    if (want_rh)
+      wave_count_add(P.n_undefined + P.nlev + lev, bad_rh);
+    if (CHECK && want_th)
+      wave_count_add(P.n_undefined + 2 * P.nlev + lev, bad_th);
+  }
+}
+
+hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream)
+{
+  if (prm.n <= 0 || prm.nlev <= 0)
+    return hipSuccess;
+  if (prm.n % 4 != 0)
+    return hipErrorInvalidValue; // callers route ragged sizes through the per-field operators
+  const int block = 256;
+  const int n4 = prm.n >> 2;
+  int gx = (n4 + block - 1) / block;
+  if (gx > 4096)
+    gx = 4096;
+  for (int l0 = 0; l0 < prm.nlev; l0 += 65535) {
+    DerivedParams p = prm;
+    const int nl = (prm.nlev - l0 > 65535) ? 65535 : (prm.nlev - l0);
+    // shift the per-level pointers; counters keep the full-batch layout
+    const size_t off = (size_t)l0 * (size_t)prm.n;
+    p.u = prm.u ? prm.u + off : nullptr;
+    p.v = prm.v ? prm.v + off : nullptr;
+    p.t = prm.t ? prm.t + off : nullptr;
+    p.q = prm.q ? prm.q + off : nullptr;
+    p.ff = prm.ff ? prm.ff + off : nullptr;
+    p.rh = prm.rh ? prm.rh + off : nullptr;
+    p.theta = prm.theta ? prm.theta + off : nullptr;
+    p.alevel = prm.alevel + l0;
+    p.blevel = prm.blevel + l0;
+    p.wind_all_defined = prm.wind_all_defined ? prm.wind_all_defined + l0 : nullptr;
+    p.thermo_all_defined = prm.thermo_all_defined ? prm.thermo_all_defined + l0 : nullptr;
+    p.n_undefined = prm.n_undefined ? prm.n_undefined + l0 : nullptr;
+    if (prm.every_level_all_defined)
+      hipLaunchKernelGGL(derived_levels_kernel<false>, dim3(gx, nl), dim3(block), 0, stream, p);
+    else
+      hipLaunchKernelGGL(derived_levels_kernel<true>, dim3(gx, nl), dim3(block), 0, stream, p);
+  }
+  return hipGetLastError();
+}
+
+} // namespace mifc

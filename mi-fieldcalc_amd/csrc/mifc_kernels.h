@@ -1,0 +1,113 @@
+// mifc_kernels.h -- host-callable launchers of the gfx950 kernels.
+// Everything here takes DEVICE pointers and a stream and only enqueues work.
+#ifndef MIFC_KERNELS_H
+#define MIFC_KERNELS_H
+
+#include <hip/hip_runtime.h>
+
+namespace mifc {
+
+typedef unsigned long long u64;
+
+// ---------------------------------------------------------------- elementwise
+enum EwiseOp {
+  EW_VECTORABS = 0, // FieldCalculations.cc:1819
+  EW_TEMP = 1,      // pleveltemp :328, hleveltemp :1046, aleveltemp :1310
+  EW_HUM = 2,       // plevelhum :400, hlevelhum :1145, alevelhum :1394
+  EW_CVHUM_TD = 3,  // cvhum compute 1..3 :1759-1785
+  EW_CVHUM_RH = 4   // cvhum compute 4,5 :1787-1811
+};
+enum PressureSource { PS_SCALAR = 0, PS_HYBRID = 1, PS_FIELD = 2 };
+enum HumKind { HUM_Q_RH = 0, HUM_RH_Q = 1, HUM_Q_TD = 2, HUM_RH_TD = 3 };
+// which extra undefined test the pressure field gets (hlevelhum :1187, alevelhum :1429)
+enum PTest { PT_NONE = 0, PT_FULL = 1 /* is_defined(p) */, PT_NEQ = 2 /* p != undef only */ };
+
+struct EwiseParams
+{
+  int op;
+  int n;          // cells per field
+  int all_defined; // input flag == ALL_DEFINED: no per-cell tests (FieldCalculations.h:47-50)
+  int count;      // 0: operator does not count / touch the flag (pleveltemp 1..3)
+  int psrc;       // PressureSource
+  int ptest;      // PTest
+  int compute;    // remapped compute (temp: 1..5, others see kernel)
+  int kind;       // HumKind
+  int from_theta; // humidity: t is potential temperature
+  float p;        // PS_SCALAR: pressure
+  float pidcp;    // PS_SCALAR: powf(p*p0inv,kappa) evaluated on the host like the reference (:347)
+  float pi;       // PS_SCALAR: host-side pi (pidcp*cp for temp, cp*pidcp for hum)
+  float tconv;    // plevelhum :436 / cvhum :1753
+  float tdconv;   // :437, :1181, :1423, :1754
+  float alevel, blevel;
+  float unit_scale; // cvhum :1746-1750
+  float undef;
+  const float* in0; // u | t
+  const float* in1; // v | hum
+  const float* in2; // ps | p field
+  float* out;
+  u64* n_undefined; // device counter (may be null when count == 0)
+};
+
+hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream);
+
+// Fused (ff, rh, theta) over levels, BASELINE.json config 2.
+struct DerivedParams
+{
+  int n;    // cells per level
+  int nlev;
+  const float *u, *v, *t, *q, *ps; // ps shared by all levels
+  const float *alevel, *blevel;    // device float[nlev]
+  float *ff, *rh, *theta;          // any may be null
+  const unsigned char* wind_all_defined;   // device u8[nlev]
+  const unsigned char* thermo_all_defined; // device u8[nlev]
+  int every_level_all_defined;             // host hint: skip all tests and counting
+  float undef;
+  u64* n_undefined; // device u64[3*nlev]: ff | rh | theta
+};
+hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream);
+
+// -------------------------------------------------------------------- stencils
+enum StencilOp {
+  ST_RELVORT = 0,    // :1843
+  ST_ABSVORT = 1,    // :1875
+  ST_DIVERGENCE = 2, // :1910
+  ST_VORTDIV = 3,    // relvort + divergence fused, two outputs
+  ST_GRAD_X = 4,     // gradient compute 1 :2013
+  ST_GRAD_Y = 5,     // 2 :2025
+  ST_GRAD_ABS = 6,   // 3 :2037
+  ST_GRAD_LAP = 7,   // 4 :2051
+  ST_GWIND_X = 8,    // plevelgwind_xcomp :638
+  ST_GWIND_Y = 9,    // plevelgwind_ycomp :674
+  ST_GVORT = 10,     // plevelgvort :708
+  ST_IGWIND = 11     // ilevelgwind :1511, two outputs
+};
+
+struct StencilParams
+{
+  int op;
+  int nx;
+  int ny_global; // rows of the whole field
+  int j0;        // global row of the first owned row (0 unless row-slab decomposed)
+  int ny_local;  // owned rows in this buffer
+  int nlev;      // fields in the batch (maps are shared)
+  // f0/f1 point at OWNED row 0; for a slab the halo rows sit directly before and after
+  const float* f0; // u | z | field | mpot
+  const float* f1; // v (uv family only)
+  const float* xmapr;
+  const float* ymapr;
+  const float* fcoriolis;
+  float* out0;
+  float* out1;   // second output (ST_VORTDIV diverg, ST_IGWIND vg); may be null
+  long in_level_stride;  // elements between consecutive levels of f0/f1
+  long out_level_stride; // same for out0/out1
+  const unsigned char* all_defined; // device u8[nlev] or null
+  int every_level_all_defined;
+  float undef;
+  u64* n_undefined; // device u64[nlev]
+};
+
+hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream);
+
+} // namespace mifc
+
+#endif // MIFC_KERNELS_H

@@ -1,0 +1,114 @@
+// Operator API of mi-fieldcalc, MI355X (gfx950) implementation.
+//
+// Source-compatible with the reference header
+// src/mi_fieldcalc/FieldCalculations.h for the operators on the accelerated
+// hot path: same namespace, names, parameter order and failure behaviour
+//   (nx, ny, const float* inputs..., scalars with "compute" last,
+//    float* output(s), ValuesDefined& fDefined /*in+out*/, float undef)
+// Every function below is a thin forwarder to the C ABI in include/mifc.h;
+// the operator bodies are HIP kernels.  Pointers are HOST pointers exactly as
+// with the reference library (fields are staged through the GPU per call); a
+// caller that keeps its fields resident in HBM uses the mifc_* entry points
+// (or the *_levels batched forms) with MIFC_MEM_DEVICE directly.
+//
+// Not provided by this build: the operators outside the hot path (stability
+// indices, field algebra, ensemble statistics, neighbourhood functions,
+// vessel icing ...); link the reference library for those.
+#ifndef MI_FIELDCALC_FIELDCALCULATIONS_H
+#define MI_FIELDCALC_FIELDCALCULATIONS_H
+
+#include "FieldDefined.h"
+
+#include <cmath>
+#include <cstddef>
+#include <string>
+#include <vector>
+
+namespace miutil {
+namespace fieldcalc {
+
+// ---- per-cell definedness test ------------------------------------------------
+inline bool is_defined(float in, float undef)
+{
+  return !std::isnan(in) && in != undef;
+}
+
+// is_defined(allDefined, in1, ..., inN, undef) for N = 1..10: true when the
+// caller vouches for the inputs (allDefined) or when every in_k is neither
+// NaN nor undef.  The last argument is always the undefined value.
+namespace detail {
+inline bool every_defined(const float* v, int n_values, float undef)
+{
+  for (int k = 0; k < n_values; ++k)
+    if (!is_defined(v[k], undef))
+      return false;
+  return true;
+}
+} // namespace detail
+
+template <typename... Floats>
+inline bool is_defined(bool allDefined, float in1, Floats... rest_then_undef)
+{
+  static_assert(sizeof...(Floats) >= 1 && sizeof...(Floats) <= 10, "is_defined(allDefined, in1..in10, undef)");
+  if (allDefined)
+    return true;
+  const float a[] = {in1, static_cast<float>(rest_then_undef)...};
+  const int n = static_cast<int>(sizeof...(Floats)); // values are a[0..n-1], undef is a[n]
+  return detail::every_defined(a, n, a[n]);
+}
+
+void copy_field(float* fout, const float* fin, size_t fsize);
+
+// ---- pressure level -----------------------------------------------------------
+bool pleveltemp(int nx, int ny, const float* tinp, float p, const std::string& unit, int compute,
+                float* tout, ValuesDefined& fDefined, float undef);
+bool plevelhum(int nx, int ny, const float* t, const float* huminp, float p, const std::string& unit, int compute,
+               float* humout, ValuesDefined& fDefined, float undef);
+bool plevelgwind_xcomp(int nx, int ny, const float* z, const float* xmapr, const float* ymapr, const float* fcoriolis,
+                       float* ug, ValuesDefined& fDefined, float undef);
+bool plevelgwind_ycomp(int nx, int ny, const float* z, const float* xmapr, const float* ymapr, const float* fcoriolis,
+                       float* vg, ValuesDefined& fDefined, float undef);
+bool plevelgvort(int nx, int ny, const float* z, const float* xmapr, const float* ymapr, const float* fcoriolis,
+                 float* gvort, ValuesDefined& fDefined, float undef);
+
+// ---- hybrid model level: p = alevel + blevel * ps[] ---------------------------
+bool hleveltemp(int nx, int ny, const float* tinp, const float* ps, float alevel, float blevel, const std::string& unit, int compute,
+                float* tout, ValuesDefined& fDefined, float undef);
+bool hlevelhum(int nx, int ny, const float* t, const float* huminp, const float* ps, float alevel, float blevel, const std::string& unit,
+               int compute, float* humout, ValuesDefined& fDefined, float undef);
+
+// ---- model level with a pressure field ----------------------------------------
+bool aleveltemp(int nx, int ny, const float* tinp, const float* p, const std::string& unit, int compute,
+                float* tout, ValuesDefined& fDefined, float undef);
+bool alevelhum(int nx, int ny, const float* t, const float* huminp, const float* p, const std::string& unit, int compute,
+               float* humout, ValuesDefined& fDefined, float undef);
+
+// ---- isentropic level ------------------------------------------------------------
+bool ilevelgwind(int nx, int ny, const float* mpot, const float* xmapr, const float* ymapr, const float* fcoriolis,
+                 float* ug, float* vg, ValuesDefined& fDefined, float undef);
+
+// ---- level independent ---------------------------------------------------------
+bool cvhum(int nx, int ny, const float* t, const float* huminp, const std::string& unit, int compute,
+           float* humout, ValuesDefined& fDefined, float undef);
+bool vectorabs(int nx, int ny, const float* u, const float* v, float* ff, ValuesDefined& fDefined, float undef);
+bool relvort(int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr,
+             float* rvort, ValuesDefined& fDefined, float undef);
+bool absvort(int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr, const float* fcoriolis,
+             float* avort, ValuesDefined& fDefined, float undef);
+bool divergence(int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr,
+                float* diverg, ValuesDefined& fDefined, float undef);
+bool gradient(int nx, int ny, const float* field, const float* xmapr, const float* ymapr, int compute,
+              float* fgrad, ValuesDefined& fDefined, float undef);
+
+// ---- extensions of this implementation (not in the reference) -----------------
+// Fused relvort + divergence for nlev levels stored [nlev][ny][nx]; xmapr/ymapr
+// are shared.  fDefined[l] in/out per level.  Either output may be null.
+bool vortdiv_levels(int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
+                    float* rvort, float* diverg, std::vector<ValuesDefined>& fDefined, float undef);
+// Last error text of the calling thread's GPU context ("" if none).
+const char* last_error();
+
+} // namespace fieldcalc
+} // namespace miutil
+
+#endif // MI_FIELDCALC_FIELDCALCULATIONS_H

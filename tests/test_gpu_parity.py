@@ -1,0 +1,328 @@
+"""GPU parity tests: the HIP kernels, called through the C ABI (include/mifc.h),
+against the CPU restatement (oracle/) on identical seeded inputs and against
+the committed golden vectors recorded from the real reference.
+
+Bar: bit-exact for the stencil operators, vectorabs, cvhum, plevel* (pure
+IEEE float/double arithmetic, table walks, powf hoisted to the host as in the
+reference); <= 1e-5 relative (BASELINE.json) for the operators that evaluate
+powf per cell on the device (hlevel/alevel theta, humidity from theta)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_util
+import gpu_util
+
+pytestmark = pytest.mark.gpu
+
+ALL, NONE, SOME = cases.ALL_DEFINED, cases.NONE_DEFINED, cases.SOME_DEFINED
+
+
+def _check_case(ctx, oracle, case, device=False, expected=None):
+    if expected is None:
+        ok_e, out_e, flag_e = cases.run_cpu(oracle, case)
+        outs_e = list(out_e) if isinstance(out_e, tuple) else [out_e]
+    else:
+        ok_e, flag_e, outs_e = expected
+    ok, out, flag = gpu_util.run_gpu(ctx, case, device=device)
+    assert ok == ok_e, case["label"]
+    if not ok_e:
+        return
+    exact = not gpu_util.uses_device_powf(case)
+    outs = list(out) if isinstance(out, tuple) else [out]
+    for a, b in zip(outs, outs_e):
+        gpu_util.compare(case, np.asarray(a), np.asarray(b), exact)
+    if exact:
+        assert flag == flag_e, case["label"]
+    else:
+        assert flag == flag_e, "%s: flag %d vs %d" % (case["label"], flag, flag_e)
+
+
+def test_native_library_is_loaded(gpu_ctx):
+    import mi_fieldcalc_amd._capi as capi
+
+    assert os.path.exists(capi.LIB_PATH)
+    with open("/proc/self/maps") as f:
+        assert "libmifc.so" in f.read()
+
+
+def test_stencils_host_pointers(gpu_ctx, oracle):
+    for case in cases.stencil_cases():
+        _check_case(gpu_ctx, oracle, case, device=False)
+
+
+def test_stencils_device_resident(gpu_ctx, oracle):
+    cs = [c for c in cases.stencil_cases(grids=[(5, 4), (64, 48), (516, 37)])]
+    for case in cs:
+        _check_case(gpu_ctx, oracle, case, device=True)
+
+
+def test_elementwise_host_pointers(gpu_ctx, oracle):
+    for case in cases.ewise_cases():
+        _check_case(gpu_ctx, oracle, case, device=False)
+
+
+def test_elementwise_device_resident(gpu_ctx, oracle):
+    for case in cases.ewise_cases(grids=[(17, 9), (64, 48)], modes=("all", "some")):
+        _check_case(gpu_ctx, oracle, case, device=True)
+
+
+def test_against_golden_vectors(gpu_ctx):
+    g, cs = golden_util.stencil_golden_cases()
+    for case in cs:
+        _check_case(gpu_ctx, None, case, expected=g.expect(case))
+    g, cs = golden_util.ewise_golden_cases()
+    for case in cs:
+        _check_case(gpu_ctx, None, case, expected=g.expect(case))
+
+
+def test_reference_known_answers(gpu_ctx):
+    """test/FieldCalculationsTest.cc:70-143 through the HIP path."""
+    from test_oracle_golden import KA_UNDEF, xlevelhum_known_answers
+
+    def call(op, args, fdef):
+        res = getattr(gpu_ctx, op)(*args, fdefined=fdef, undef=KA_UNDEF)
+        if res is None:
+            return False, float("nan"), -1
+        out, flag = res
+        return True, float(out[0, 0]), flag
+
+    xlevelhum_known_answers(call)
+
+
+def test_aleveltemp_theta_within_4ulp(gpu_ctx):
+    """test/FieldCalculationsTest.cc:145-170 through the HIP path (device powf)."""
+    from test_oracle_golden import aleveltemp_performance_inputs, ulp_diff
+
+    n, tk, p = aleveltemp_performance_inputs()
+    res = gpu_ctx.aleveltemp(tk.reshape(n, 1), p.reshape(n, 1), "kelvin", 3, fdefined=ALL, undef=np.float32(1e30))
+    assert res is not None
+    th, flag = res
+    p0inv = np.float32(1.0 / 1000.0)
+    kappa = np.float32(287.0) / np.float32(1004.0)
+    ex = tk / np.power(p * p0inv, kappa, dtype=np.float32)
+    assert ulp_diff(th.reshape(-1), ex).max() <= 4
+
+
+# ------------------------------------------------------------------ batched levels
+def _levels_inputs(nx, ny, nlev, seed, mixed=True):
+    import mi_fieldcalc_amd.synth as synth
+
+    xm, ym, fc = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, seed, nlev=nlev)
+    flags = np.full(nlev, SOME, np.int32)
+    if mixed:
+        for l in range(nlev):
+            kind = l % 4
+            if kind == 0:
+                flags[l] = ALL
+            elif kind == 1:
+                u[l] = synth.sprinkle_undef(u[l], seed + l, 0.02)
+                v[l] = synth.sprinkle_undef(v[l], seed + 100 + l, 0.02)
+            elif kind == 2:
+                u[l] = cases.UNDEF
+                v[l] = cases.UNDEF
+            else:  # flag lies: ALL_DEFINED but undefined values present
+                flags[l] = ALL
+                u[l] = synth.sprinkle_undef(u[l], seed + l, 0.02)
+    else:
+        flags[:] = ALL
+    return u, v, xm, ym, flags
+
+
+def _expect_levels(oracle, u, v, xm, ym, flags):
+    nlev, ny, nx = u.shape
+    rv = np.empty_like(u)
+    dv = np.empty_like(u)
+    fo = np.empty(nlev, np.int32)
+    for l in range(nlev):
+        ok, o, f1 = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=int(flags[l]))
+        assert ok
+        rv[l] = o
+        ok, o, f2 = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=int(flags[l]))
+        dv[l] = o
+        assert f1 == f2
+        fo[l] = f1
+    return rv, dv, fo
+
+
+@pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 9), (516, 70, 6), (260, 11, 5), (17, 9, 7), (1440, 75, 5)])
+@pytest.mark.parametrize("tune", ["", "R=7,D=0", "R=5,D=1,NT=1", "R=64,D=3"])
+def test_vortdiv_levels_matches_per_level_reference_calls(gpu_ctx, oracle, nx, ny, nlev, tune, monkeypatch):
+    import torch
+
+    if tune:
+        monkeypatch.setenv("MIFC_VORTDIV_TUNE", tune)
+    u, v, xm, ym, flags = _levels_inputs(nx, ny, nlev, 4242 + nx)
+    rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
+    # host pointers
+    (rv, dv), fo = gpu_ctx.vortdiv_levels(u, v, xm, ym, fdefined=flags)
+    assert cases.same_bits(rv, rv_e) and cases.same_bits(dv, dv_e)
+    assert np.array_equal(fo, fo_e)
+    # device resident, single outputs
+    du, dvv, dxm, dym = (torch.from_numpy(a).cuda() for a in (u, v, xm, ym))
+    (rv2, none), fo2 = gpu_ctx.vortdiv_levels(du, dvv, dxm, dym, fdefined=flags, want=("rvort",))
+    assert none is None and cases.same_bits(rv2.cpu().numpy(), rv_e) and np.array_equal(fo2, fo_e)
+    (none, dv2), fo3 = gpu_ctx.vortdiv_levels(du, dvv, dxm, dym, fdefined=flags, want=("diverg",))
+    assert none is None and cases.same_bits(dv2.cpu().numpy(), dv_e) and np.array_equal(fo3, fo_e)
+
+
+def test_vortdiv_levels_all_defined_fast_path(gpu_ctx, oracle):
+    u, v, xm, ym, flags = _levels_inputs(256, 40, 8, 777, mixed=False)
+    rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
+    (rv, dv), fo = gpu_ctx.vortdiv_levels(u, v, xm, ym, fdefined=flags)
+    assert cases.same_bits(rv, rv_e) and cases.same_bits(dv, dv_e) and np.array_equal(fo, fo_e)
+
+
+def test_vortdiv_enqueue_counts(gpu_ctx, oracle):
+    import torch
+
+    nx, ny, nlev = 128, 33, 6
+    u, v, xm, ym, flags = _levels_inputs(nx, ny, nlev, 99)
+    rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
+    du, dvv, dxm, dym = (torch.from_numpy(a).cuda() for a in (u, v, xm, ym))
+    rv = torch.empty_like(du)
+    dv = torch.empty_like(du)
+    cnt = torch.full((nlev,), -1, dtype=torch.int64, device="cuda")
+    gpu_ctx.use_torch_stream()
+    try:
+        assert gpu_ctx.vortdiv_levels_enqueue(du, dvv, dxm, dym, rv, dv, fdefined=flags, n_undefined=cnt)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_stream(None)
+    import mi_fieldcalc_amd as fc
+
+    fo = np.array([fc.classify(int(c), nx * ny - 2 * nx) for c in cnt.cpu().numpy()])
+    fo = np.where(flags == ALL, ALL, fo)  # ALL_DEFINED levels run without tests: count stays 0
+    assert np.array_equal(fo, fo_e)
+    assert cases.same_bits(rv.cpu().numpy(), rv_e) and cases.same_bits(dv.cpu().numpy(), dv_e)
+
+
+# ------------------------------------------------------------------ row slabs
+@pytest.mark.parametrize("nx,ny,nslab", [(64, 40, 4), (260, 23, 3), (512, 64, 8), (33, 17, 2)])
+@pytest.mark.parametrize("mode", ["all", "some"])
+def test_vortdiv_row_slabs_equal_whole_field(gpu_ctx, oracle, nx, ny, nslab, mode):
+    """Config 4 decomposition exercised on one GPU with a loop-back halo 'exchange'."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+    from mi_fieldcalc_amd.sharding import slab_rows
+
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 31337 + nx)
+    (u, v), flag = cases._apply_mode([u, v], mode, 5, 0.03)
+    ok, rv_e, f1 = oracle.call("relvort", nx, ny, u, v, xm, ym, fdefined=flag)
+    ok, dv_e, f2 = oracle.call("divergence", nx, ny, u, v, xm, ym, fdefined=flag)
+    rv = np.empty_like(u)
+    dv = np.empty_like(u)
+    total = 0
+    gpu_ctx.use_torch_stream()
+    try:
+        for r in range(nslab):
+            j0, nloc = slab_rows(ny, nslab, r)
+            uh = np.zeros((nloc + 2, nx), np.float32)
+            vh = np.zeros((nloc + 2, nx), np.float32)
+            uh[1:-1] = u[j0:j0 + nloc]
+            vh[1:-1] = v[j0:j0 + nloc]
+            if j0 > 0:
+                uh[0], vh[0] = u[j0 - 1], v[j0 - 1]
+            if j0 + nloc < ny:
+                uh[-1], vh[-1] = u[j0 + nloc], v[j0 + nloc]
+            t = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (uh, vh, xm[j0:j0 + nloc], ym[j0:j0 + nloc])]
+            o_rv = torch.empty((nloc, nx), dtype=torch.float32, device="cuda")
+            o_dv = torch.empty_like(o_rv)
+            cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+            assert gpu_ctx.vortdiv_slab_enqueue(nx, ny, j0, nloc, t[0], t[1], t[2], t[3], o_rv, o_dv, fdefined_in=flag, n_undefined=cnt)
+            torch.cuda.synchronize()
+            rv[j0:j0 + nloc] = o_rv.cpu().numpy()
+            dv[j0:j0 + nloc] = o_dv.cpu().numpy()
+            total += int(cnt.item())
+    finally:
+        gpu_ctx.set_stream(None)
+    assert cases.same_bits(rv, rv_e) and cases.same_bits(dv, dv_e)
+    got_flag = ALL if flag == ALL else fc.classify(total, nx * ny - 2 * nx)
+    assert got_flag == f1 == f2
+
+
+# ------------------------------------------------------------------ fused derived variables
+@pytest.mark.parametrize("mode", ["all", "some"])
+def test_hlevel_derived_levels(gpu_ctx, oracle, mode):
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 64, 36, 5
+    u, v = synth.wind(nx, ny, 11, nlev=nlev)
+    t, q, ps = synth.thermo(nx, ny, 12, nlev=nlev)
+    a, b = synth.hybrid_levels(nlev)
+    fw = np.full(nlev, ALL if mode == "all" else SOME, np.int32)
+    ft = fw.copy()
+    if mode == "some":
+        for l in range(nlev):
+            u[l] = synth.sprinkle_undef(u[l], 50 + l, 0.02)
+            t[l] = synth.sprinkle_undef(t[l], 60 + l, 0.02)
+            q[l] = synth.sprinkle_undef(q[l], 70 + l, 0.02)
+        ps = synth.sprinkle_undef(ps, 80, 0.02, nan_every=0)
+        t[0, 0, :8] = 400.0  # outside the ewt table: rh undefined, theta still defined
+    res, flags = gpu_ctx.hlevel_derived_levels(u, v, t, q, ps, a, b, fdef_wind=fw, fdef_thermo=ft)
+    for l in range(nlev):
+        ok, ff_e, f_ff = oracle.call("vectorabs", nx, ny, u[l], v[l], fdefined=int(fw[l]))
+        ok, rh_e, f_rh = oracle.call("hlevelhum", nx, ny, t[l], q[l], ps, float(a[l]), float(b[l]), "", 1, fdefined=int(ft[l]))
+        ok, th_e, f_th = oracle.call("hleveltemp", nx, ny, t[l], ps, float(a[l]), float(b[l]), "", 3, fdefined=int(ft[l]))
+        case = dict(label="derived-l%d" % l, undef=cases.UNDEF)
+        gpu_util.compare(case, res["ff"][l], ff_e, True)
+        gpu_util.compare(case, res["rh"][l], rh_e, True)   # T,q -> RH: no powf involved
+        gpu_util.compare(case, res["theta"][l], th_e, False)  # theta: device powf, 1e-5 relative
+        assert (flags["ff"][l], flags["rh"][l], flags["theta"][l]) == (f_ff, f_rh, f_th)
+    # bad hybrid level -> false
+    assert gpu_ctx.hlevel_derived_levels(u, v, t, q, ps, -a, b, fdef_wind=fw, fdef_thermo=ft) is None
+
+
+# ------------------------------------------------------------------ headline size
+def test_headline_1440x720x137_properties(gpu_ctx, oracle):
+    """Full BASELINE.json configuration on the device: sampled levels against the
+    oracle bit for bit, every level through a size-independent property (the
+    fused row-sliding kernel and the one-lane-per-cell kernel are independent
+    implementations and must agree on every bit of every level)."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 1440, 720, 137
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    dxm, dym = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+    du, dv = synth.device_wind(nx, ny, nlev, 0x5EED0000 + 3000, "cuda")
+    flags = np.full(nlev, ALL, np.int32)
+    (rv, dg), fo = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
+    assert np.all(fo == ALL)
+    for l in (0, 1, 68, 136):
+        ul, vl = du[l].cpu().numpy(), dv[l].cpu().numpy()
+        ok, e, _ = oracle.call("relvort", nx, ny, ul, vl, xm, ym, fdefined=ALL)
+        assert cases.same_bits(rv[l].cpu().numpy(), e)
+        ok, e, _ = oracle.call("divergence", nx, ny, ul, vl, xm, ym, fdefined=ALL)
+        assert cases.same_bits(dg[l].cpu().numpy(), e)
+    os.environ["MIFC_FORCE_CELL_KERNEL"] = "1"
+    try:
+        (rv2, dg2), _ = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
+    finally:
+        del os.environ["MIFC_FORCE_CELL_KERNEL"]
+    assert torch.equal(rv.view(torch.int32), rv2.view(torch.int32))
+    assert torch.equal(dg.view(torch.int32), dg2.view(torch.int32))
+    # edge rule of fillEdges on every level: rows 0 / ny-1 and columns 0 / nx-1 are copies
+    assert torch.equal(rv[:, 0, :], rv[:, 1, :]) and torch.equal(rv[:, -1, :], rv[:, -2, :])
+    assert torch.equal(dg[:, :, 0], dg[:, :, 1]) and torch.equal(dg[:, :, -1], dg[:, :, -2])
+    # with undefined cells sprinkled in: counts per level agree between the two kernels
+    du[:, 100:110, 200:260] = float(cases.UNDEF)
+    flags[:] = SOME
+    (rv3, dg3), fo3 = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
+    os.environ["MIFC_FORCE_CELL_KERNEL"] = "1"
+    try:
+        (rv4, dg4), fo4 = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
+    finally:
+        del os.environ["MIFC_FORCE_CELL_KERNEL"]
+    assert np.array_equal(fo3, fo4) and np.all(fo3 == SOME)
+    assert torch.equal(rv3.view(torch.int32), rv4.view(torch.int32)) and torch.equal(dg3.view(torch.int32), dg4.view(torch.int32))
+    l = 5
+    ok, e, f = oracle.call("relvort", nx, ny, du[l].cpu().numpy(), dv[l].cpu().numpy(), xm, ym, fdefined=SOME)
+    assert cases.same_bits(rv3[l].cpu().numpy(), e) and f == fo3[l]
