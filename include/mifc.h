@@ -61,9 +61,12 @@ int mifc_device_count(void);
 mifc_ctx* mifc_create(int device);
 void mifc_destroy(mifc_ctx* ctx);
 const char* mifc_last_error(const mifc_ctx* ctx);
-/* Run subsequent work on a caller-owned hipStream_t (e.g. the PyTorch current
- * stream); NULL switches back to the context's own stream. */
+/* Run subsequent work on a caller-owned hipStream_t, e.g. the PyTorch current
+ * stream.  NULL means HIP's null (default) stream -- which is what PyTorch's
+ * default stream is.  mifc_use_own_stream() switches back to the context's own
+ * non-blocking stream (the initial state). */
 int mifc_set_stream(mifc_ctx* ctx, void* hip_stream);
+int mifc_use_own_stream(mifc_ctx* ctx);
 int mifc_synchronize(mifc_ctx* ctx);
 /* Device memory for callers that do not link HIP themselves. */
 void* mifc_device_alloc(mifc_ctx* ctx, size_t bytes);

@@ -109,10 +109,14 @@ class Context:
         return s.decode() if s else ""
 
     def set_stream(self, stream):
-        """stream: raw hipStream_t address, a torch.cuda.Stream, or None."""
-        if stream is not None and hasattr(stream, "cuda_stream"):
+        """stream: raw hipStream_t address (0 = HIP's default stream), a
+        torch.cuda.Stream, or None to go back to the context's own stream."""
+        if stream is None:
+            self._lib.mifc_use_own_stream(self._ctx)
+            return
+        if hasattr(stream, "cuda_stream"):
             stream = stream.cuda_stream
-        self._lib.mifc_set_stream(self._ctx, ctypes.c_void_p(stream or 0))
+        self._lib.mifc_set_stream(self._ctx, ctypes.c_void_p(int(stream)))
 
     def use_torch_stream(self):
         import torch
@@ -124,6 +128,16 @@ class Context:
             raise RuntimeError(self.last_error())
 
     # ------------------------------------------------------------ call helper
+    def _bind_stream(self, memkind):
+        """Fields resident on the device come from PyTorch: run on torch's
+        current stream so that the kernels are ordered after whatever produced
+        the inputs (and before whatever consumes the outputs).  Host-pointer
+        calls use the context's own stream."""
+        if memkind == MEM_DEVICE:
+            self.use_torch_stream()
+        else:
+            self.set_stream(None)
+
     def _call(self, name, args):
         rc = getattr(self._lib, name)(self._ctx, *args)
         if not rc and self.last_error():
@@ -148,6 +162,7 @@ class Context:
                 outs[k] = _empty_like(ref)
         oa = [_Arg(o) for o in outs]
         mk = _memkind(fa + oa)
+        self._bind_stream(mk)
         fd = ctypes.c_int(int(fdefined))
         args = [nx, ny] + [a.addr for a in fa] + list(scalars) + [a.addr for a in oa] + [ctypes.addressof(fd), float(undef), mk]
         if not self._call(name, args):
@@ -225,6 +240,7 @@ class Context:
             diverg = _empty_like(u)
         ar, ad = _Arg(rvort, allow_none=True), _Arg(diverg, allow_none=True)
         mk = _memkind([au, av, ax, ay, ar, ad])
+        self._bind_stream(mk)
         flags = np.full(nlev, SOME_DEFINED, dtype=np.int32) if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
         rc = self._call(
             "mifc_vortdiv_levels",
@@ -241,6 +257,7 @@ class Context:
         ar, ad = _Arg(rvort, allow_none=True), _Arg(diverg, allow_none=True)
         nlev, ny, nx = au.shape
         flags = None if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
+        self._bind_stream(MEM_DEVICE)
         rc = self._call(
             "mifc_vortdiv_levels_enqueue",
             [
@@ -264,6 +281,7 @@ class Context:
         a = {k: _Arg(x, allow_none=True) for k, x in dict(u=u, v=v, t=t, q=q, ps=ps).items()}
         o = {k: _Arg(out.get(k), allow_none=True) for k in ("ff", "rh", "theta")}
         mk = _memkind(list(a.values()) + list(o.values()))
+        self._bind_stream(mk)
         al = np.ascontiguousarray(alevel if alevel is not None else np.zeros(nlev), dtype=np.float32).reshape(nlev)
         bl = np.ascontiguousarray(blevel if blevel is not None else np.ones(nlev), dtype=np.float32).reshape(nlev)
         fw = np.full(nlev, SOME_DEFINED, np.int32) if fdef_wind is None else np.array(fdef_wind, np.int32).reshape(nlev).copy()
@@ -292,6 +310,7 @@ class Context:
         bl = np.ascontiguousarray(blevel, dtype=np.float32).reshape(nlev)
         fw = None if fdef_wind is None else np.array(fdef_wind, np.int32).reshape(nlev).copy()
         ft = None if fdef_thermo is None else np.array(fdef_thermo, np.int32).reshape(nlev).copy()
+        self._bind_stream(MEM_DEVICE)
         rc = self._call(
             "mifc_hlevel_derived_levels_enqueue",
             [nx, ny, nlev] + [x.addr for x in a] + [al.ctypes.data, bl.ctypes.data] + [x.addr for x in o]
@@ -303,6 +322,7 @@ class Context:
                              undef=UNDEF, n_undefined=None):
         """Row-slab form (see include/mifc.h); all tensors on the device."""
         a = [_Arg(x, allow_none=True) for x in (u_halo, v_halo, xmapr, ymapr, rvort, diverg)]
+        self._bind_stream(MEM_DEVICE)
         rc = self._call(
             "mifc_vortdiv_slab_enqueue",
             [int(nx), int(ny_global), int(j0), int(ny_local)] + [x.addr for x in a]

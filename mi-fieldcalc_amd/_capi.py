@@ -34,6 +34,7 @@ SIGNATURES = {
     "mifc_destroy": (None, ["ctx"]),
     "mifc_last_error": ("s", ["ctx"]),
     "mifc_set_stream": ("i", ["ctx", "p"]),
+    "mifc_use_own_stream": ("i", ["ctx"]),
     "mifc_synchronize": ("i", ["ctx"]),
     "mifc_device_alloc": ("p", ["ctx", "z"]),
     "mifc_device_free": ("i", ["ctx", "p"]),
@@ -79,6 +80,15 @@ def load_library(path=LIB_PATH):
             "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
             "or make -C mi-fieldcalc_amd). There is no CPU fallback." % path
         )
+    # PyTorch-ROCm wheels bundle their own HIP runtime under the same SONAME
+    # (libamdhip64.so.7).  A process must hold ONE runtime, or the second one
+    # finds no device: when torch is importable, load it first so that
+    # libmifc.so binds to the runtime torch already brought in and device
+    # pointers / streams can be shared.  Plain C/C++ callers use /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -409,7 +409,15 @@ int mifc_set_stream(mifc_ctx* c, void* hip_stream)
   if (!c)
     return 0;
   c->err.clear();
-  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  c->stream = static_cast<hipStream_t>(hip_stream); // null = HIP's default stream
+  return 1;
+}
+
+int mifc_use_own_stream(mifc_ctx* c)
+{
+  if (!c)
+    return 0;
+  c->stream = c->own_stream;
   return 1;
 }
 

@@ -91,12 +91,21 @@ __device__ __forceinline__ float clamp_rh(float rh)
   return rh;
 }
 
-// FieldCalculations.cc:308-311.  Device libm powf: within a few ulp of glibc's
-// (not bit-identical); parity for the theta / humidity-from-theta variants is
-// therefore <= 1e-5 relative, as BASELINE.json states, not bit-exact.
+// FieldCalculations.cc:308-311: powf(p * p0inv, kappa).
+// The reference calls glibc's powf, which evaluates in double and returns a
+// nearly correctly rounded float.  The device's float powf is several ulp off,
+// and the saturation-pressure table amplifies a temperature error (up to
+// ~0.3 per kelvin at its cold end), so the power is taken in double here:
+// exp2(kappa * log2(x)) with the double-precision device functions rounds to
+// the correctly rounded float except in rare near-halfway cases.  Agreement
+// with glibc is therefore "identical in almost every cell, 1 ulp otherwise";
+// the parity bound for the operators that use it is 1e-5 relative
+// (BASELINE.json), not bit-exact.  Special values behave like powf with a
+// positive non-integer exponent: x<0 -> NaN, 0 -> 0, inf -> inf, NaN -> NaN.
 __device__ __forceinline__ float pidcp_of(float p)
 {
-  return powf(p * MIFC_K_P0INV, MIFC_K_KAPPA);
+  const float x = p * MIFC_K_P0INV;
+  return (float)exp2((double)MIFC_K_KAPPA * log2((double)x));
 }
 
 // The point functions return false where the table does not cover tk
@@ -168,7 +177,7 @@ __device__ __forceinline__ bool tk_rh_td(const float* tab, float tk, float rh100
 // math_util.h:57-60: sqrt(x*x + y*y) in float, correctly rounded sqrt, no fma
 __device__ __forceinline__ float absval(float x, float y)
 {
-  return __fsqrt_rn(x * x + y * y);
+  return sqrtf(x * x + y * y);
 }
 
 // ---- stencil point formulas (double-promoted; inputs are float differences)

@@ -137,7 +137,15 @@ def run_cpu(lib, case, prefill=None):
     return lib.call(case["op"], case["nx"], case["ny"], *case["args"], fdefined=case["fdefined"], undef=case["undef"], outs=outs)
 
 
-def same_bits(a, b):
-    a = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
-    b = np.ascontiguousarray(b, dtype=np.float32).view(np.uint32)
-    return np.array_equal(a, b)
+def same_bits(a, b, nan_payload=True):
+    """Bit-for-bit equality.  nan_payload=False: a NaN matches any NaN (sign and
+    payload of an arithmetic NaN are an ISA property, x86 SSE gives 0xFFC00000,
+    gfx950 0x7FC00000; NaNs only arise when a caller passes ALL_DEFINED for a
+    field that holds NaN) -- used for CPU-vs-GPU comparisons only."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    ai, bi = a.view(np.uint32), b.view(np.uint32)
+    if nan_payload:
+        return np.array_equal(ai, bi)
+    an, bn = np.isnan(a), np.isnan(b)
+    return np.array_equal(an, bn) and np.array_equal(ai[~an], bi[~bn])

@@ -159,21 +159,21 @@ def test_vortdiv_levels_matches_per_level_reference_calls(gpu_ctx, oracle, nx, n
     rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
     # host pointers
     (rv, dv), fo = gpu_ctx.vortdiv_levels(u, v, xm, ym, fdefined=flags)
-    assert cases.same_bits(rv, rv_e) and cases.same_bits(dv, dv_e)
+    assert cases.same_bits(rv, rv_e, nan_payload=False) and cases.same_bits(dv, dv_e, nan_payload=False)
     assert np.array_equal(fo, fo_e)
     # device resident, single outputs
     du, dvv, dxm, dym = (torch.from_numpy(a).cuda() for a in (u, v, xm, ym))
     (rv2, none), fo2 = gpu_ctx.vortdiv_levels(du, dvv, dxm, dym, fdefined=flags, want=("rvort",))
-    assert none is None and cases.same_bits(rv2.cpu().numpy(), rv_e) and np.array_equal(fo2, fo_e)
+    assert none is None and cases.same_bits(rv2.cpu().numpy(), rv_e, nan_payload=False) and np.array_equal(fo2, fo_e)
     (none, dv2), fo3 = gpu_ctx.vortdiv_levels(du, dvv, dxm, dym, fdefined=flags, want=("diverg",))
-    assert none is None and cases.same_bits(dv2.cpu().numpy(), dv_e) and np.array_equal(fo3, fo_e)
+    assert none is None and cases.same_bits(dv2.cpu().numpy(), dv_e, nan_payload=False) and np.array_equal(fo3, fo_e)
 
 
 def test_vortdiv_levels_all_defined_fast_path(gpu_ctx, oracle):
     u, v, xm, ym, flags = _levels_inputs(256, 40, 8, 777, mixed=False)
     rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
     (rv, dv), fo = gpu_ctx.vortdiv_levels(u, v, xm, ym, fdefined=flags)
-    assert cases.same_bits(rv, rv_e) and cases.same_bits(dv, dv_e) and np.array_equal(fo, fo_e)
+    assert cases.same_bits(rv, rv_e, nan_payload=False) and cases.same_bits(dv, dv_e, nan_payload=False) and np.array_equal(fo, fo_e)
 
 
 def test_vortdiv_enqueue_counts(gpu_ctx, oracle):
@@ -197,7 +197,7 @@ def test_vortdiv_enqueue_counts(gpu_ctx, oracle):
     fo = np.array([fc.classify(int(c), nx * ny - 2 * nx) for c in cnt.cpu().numpy()])
     fo = np.where(flags == ALL, ALL, fo)  # ALL_DEFINED levels run without tests: count stays 0
     assert np.array_equal(fo, fo_e)
-    assert cases.same_bits(rv.cpu().numpy(), rv_e) and cases.same_bits(dv.cpu().numpy(), dv_e)
+    assert cases.same_bits(rv.cpu().numpy(), rv_e, nan_payload=False) and cases.same_bits(dv.cpu().numpy(), dv_e, nan_payload=False)
 
 
 # ------------------------------------------------------------------ row slabs
@@ -242,7 +242,7 @@ def test_vortdiv_row_slabs_equal_whole_field(gpu_ctx, oracle, nx, ny, nslab, mod
             total += int(cnt.item())
     finally:
         gpu_ctx.set_stream(None)
-    assert cases.same_bits(rv, rv_e) and cases.same_bits(dv, dv_e)
+    assert cases.same_bits(rv, rv_e, nan_payload=False) and cases.same_bits(dv, dv_e, nan_payload=False)
     got_flag = ALL if flag == ALL else fc.classify(total, nx * ny - 2 * nx)
     assert got_flag == f1 == f2
 
@@ -299,9 +299,9 @@ def test_headline_1440x720x137_properties(gpu_ctx, oracle):
     for l in (0, 1, 68, 136):
         ul, vl = du[l].cpu().numpy(), dv[l].cpu().numpy()
         ok, e, _ = oracle.call("relvort", nx, ny, ul, vl, xm, ym, fdefined=ALL)
-        assert cases.same_bits(rv[l].cpu().numpy(), e)
+        assert cases.same_bits(rv[l].cpu().numpy(), e, nan_payload=False)
         ok, e, _ = oracle.call("divergence", nx, ny, ul, vl, xm, ym, fdefined=ALL)
-        assert cases.same_bits(dg[l].cpu().numpy(), e)
+        assert cases.same_bits(dg[l].cpu().numpy(), e, nan_payload=False)
     os.environ["MIFC_FORCE_CELL_KERNEL"] = "1"
     try:
         (rv2, dg2), _ = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
@@ -325,4 +325,4 @@ def test_headline_1440x720x137_properties(gpu_ctx, oracle):
     assert torch.equal(rv3.view(torch.int32), rv4.view(torch.int32)) and torch.equal(dg3.view(torch.int32), dg4.view(torch.int32))
     l = 5
     ok, e, f = oracle.call("relvort", nx, ny, du[l].cpu().numpy(), dv[l].cpu().numpy(), xm, ym, fdefined=SOME)
-    assert cases.same_bits(rv3[l].cpu().numpy(), e) and f == fo3[l]
+    assert cases.same_bits(rv3[l].cpu().numpy(), e, nan_payload=False) and f == fo3[l]
