@@ -329,3 +329,9 @@ class Context:
             + [int(fdefined_in), float(undef), None if n_undefined is None else n_undefined.data_ptr()],
         )
         return bool(rc)
+
+    def bench_stream2(self, variant, blocks, dst0, dst1, src0, src1):
+        """Bandwidth yardstick (see include/mifc.h); device tensors."""
+        self._bind_stream(MEM_DEVICE)
+        n = src0.numel()
+        return bool(self._call("mifc_bench_stream2", [int(variant), int(blocks), dst0.data_ptr(), dst1.data_ptr(), src0.data_ptr(), src1.data_ptr(), n]))

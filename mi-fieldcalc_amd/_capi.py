@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmifc.so")
+LIB_PATH = os.environ.get("MIFC_LIB_PATH") or os.path.join(_HERE, "libmifc.so")  # override: experiments in tools/ only
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -71,6 +71,8 @@ SIGNATURES = {
         ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "p", "pi", "pi", "f", "pu"],
     ),
     "mifc_vortdiv_slab_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu"]),
+    # diagnostics
+    "mifc_bench_stream2": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "z"]),
 }
 
 

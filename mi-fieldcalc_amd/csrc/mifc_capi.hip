@@ -1048,4 +1048,15 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny
   return 1;
 }
 
+int mifc_bench_stream2(mifc_ctx* c, int variant, int blocks, float* dst0, float* dst1, const float* src0, const float* src1, size_t n_floats)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (n_floats % 4 != 0)
+    return 0;
+  MIFC_HIP(c, mifc::launch_stream2(variant, blocks, dst0, dst1, src0, src1, n_floats, c->stream));
+  return 1;
+}
+
 } // extern "C"

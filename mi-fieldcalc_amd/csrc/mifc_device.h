@@ -181,6 +181,14 @@ __device__ __forceinline__ float absval(float x, float y)
 }
 
 // ---- stencil point formulas (double-promoted; inputs are float differences)
+#ifdef MIFC_EXPERIMENT_F32_COMBINE
+// NOT parity-correct: float-only combine, exists solely so that tools/ can
+// measure how much of the kernel time is the fp64 pipe (never built into the product)
+__device__ __forceinline__ float f_relvort(float xm, float ym, float dvdx, float dudy) { return 0.5f * xm * dvdx - 0.5f * ym * dudy; }
+__device__ __forceinline__ float f_diverg(float xm, float ym, float dudx, float dvdy) { return 0.5f * xm * dudx + 0.5f * ym * dvdy; }
+#define MIFC_SKIP_F64_COMBINE 1
+#endif
+#ifndef MIFC_SKIP_F64_COMBINE
 // FieldCalculations.cc:1862
 __device__ __forceinline__ float f_relvort(float xm, float ym, float dvdx, float dudy)
 {
@@ -196,6 +204,7 @@ __device__ __forceinline__ float f_diverg(float xm, float ym, float dudx, float 
 {
   return (float)(0.5 * (double)xm * (double)dudx + 0.5 * (double)ym * (double)dvdy);
 }
+#endif
 
 // ---- undefined-cell counting: one atomic per wave, none when nothing to add
 __device__ __forceinline__ void wave_count_add(u64* counter, unsigned int my_count)

@@ -340,3 +340,62 @@ hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream)
 }
 
 } // namespace mifc
+
+// ----------------------------------------------------------------------------
+// Bandwidth yardstick (diagnostic): streams two input fields into two output
+// fields with the same 16-byte-per-lane access shape as the operators and no
+// arithmetic.  bench.py / tools report operator bandwidth next to this number,
+// measured on the same device in the same process.
+namespace mifc {
+namespace {
+template <int VARIANT>
+__global__ __launch_bounds__(256) void stream2_kernel(float* __restrict__ d0, float* __restrict__ d1, const float* __restrict__ s0,
+                                                      const float* __restrict__ s1, size_t n4)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f* a = reinterpret_cast<const v4f*>(s0);
+  const v4f* b = reinterpret_cast<const v4f*>(s1);
+  v4f* x = reinterpret_cast<v4f*>(d0);
+  v4f* y = reinterpret_cast<v4f*>(d1);
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+    v4f va, vb;
+    if (VARIANT == 2) {
+      va = __builtin_nontemporal_load(a + q);
+      vb = __builtin_nontemporal_load(b + q);
+    } else {
+      va = a[q];
+      vb = b[q];
+    }
+    if (VARIANT >= 1) {
+      __builtin_nontemporal_store(va, x + q);
+      __builtin_nontemporal_store(vb, y + q);
+    } else {
+      x[q] = va;
+      y[q] = vb;
+    }
+  }
+}
+} // namespace
+
+hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const float* s0, const float* s1, size_t n_floats, hipStream_t stream)
+{
+  const size_t n4 = n_floats / 4;
+  if (blocks <= 0) {
+    const size_t want = (n4 + 255) / 256;
+    blocks = (int)(want > 0x7fffffff ? 0x7fffffff : want);
+  }
+  switch (variant) {
+  case 0:
+    hipLaunchKernelGGL(stream2_kernel<0>, dim3(blocks), dim3(256), 0, stream, d0, d1, s0, s1, n4);
+    break;
+  case 1:
+    hipLaunchKernelGGL(stream2_kernel<1>, dim3(blocks), dim3(256), 0, stream, d0, d1, s0, s1, n4);
+    break;
+  default:
+    hipLaunchKernelGGL(stream2_kernel<2>, dim3(blocks), dim3(256), 0, stream, d0, d1, s0, s1, n4);
+    break;
+  }
+  return hipGetLastError();
+}
+} // namespace mifc

@@ -108,6 +108,9 @@ struct StencilParams
 
 hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream);
 
+// diagnostic: two-in / two-out streaming copy (bandwidth yardstick)
+hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const float* s0, const float* s1, size_t n_floats, hipStream_t stream);
+
 } // namespace mifc
 
 #endif // MIFC_KERNELS_H

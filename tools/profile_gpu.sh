@@ -1,0 +1,22 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): kernel-trace stats and, in SEPARATE runs,
+# the PMC counters for HBM traffic / L2 behaviour of the headline kernel.
+#   bash tools/profile_gpu.sh [tag]
+# Summaries land under gpurun_out/prof_<tag>/; copy what is to be judged into profiles/.
+set -u
+TAG=${1:-r01}
+OUT=gpurun_out/prof_${TAG}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+CMD="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
+echo "trace rc=$?"
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCP_TCC_READ_REQ_sum TCC_REQ_sum" "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES"; do
+  NAME=$(echo "$C" | tr ' ' '_')
+  rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$NAME" -- $CMD > "$OUT/pmc_$NAME.log" 2>&1
+  echo "pmc $C rc=$?"
+done
+# compact summaries
+python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"

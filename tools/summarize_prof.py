@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (kernel-trace --stats and --pmc passes) of
+tools/profile_gpu.sh into a short text summary + profiles/pmc_traffic.json-style
+numbers.  Usage: python tools/summarize_prof.py gpurun_out/prof_<tag>"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pattern):
+    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+
+
+def main():
+    root = sys.argv[1]
+    # ---- kernel stats
+    for f in find(os.path.join(root, "trace"), "*kernel_stats.csv"):
+        print("== kernel stats:", os.path.relpath(f, root))
+        with open(f) as fh:
+            rows = list(csv.DictReader(fh))
+        for r in rows[:12]:
+            name = r.get("Name", "")[:90]
+            print("  %-90s calls=%s avg_ns=%s min_ns=%s max_ns=%s pct=%s" % (
+                name, r.get("Calls"), r.get("AverageNs"), r.get("MinNs"), r.get("MaxNs"), r.get("Percentage")))
+    # ---- counters: average per dispatch of the headline kernel
+    per_counter = defaultdict(list)
+    regs = {}
+    for f in find(root, "*counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                kn = r.get("Kernel_Name", "")
+                if "vortdiv_rows_kernel" not in kn:
+                    continue
+                per_counter[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                regs = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
+    if per_counter:
+        print("== PMC, average per dispatch of vortdiv_rows_kernel")
+        avg = {k: sum(v) / len(v) for k, v in per_counter.items()}
+        for k in sorted(avg):
+            print("  %-28s %.6g  (n=%d)" % (k, avg[k], len(per_counter[k])))
+        print("  registers/launch:", regs)
+        out = {}
+        if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+            # MI355X_MICROARCH.md, HBM: FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+            # reports exactly half of the bytes of a wide (16 B/lane) coalesced read stream -> x2;
+            # WRITE_SIZE is exact for 16 B/lane streaming stores.
+            rd = avg["FETCH_SIZE"] * 1024.0 * 2.0
+            wr = avg["WRITE_SIZE"] * 1024.0
+            out = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+                   "raw": {"FETCH_SIZE_KiB": avg["FETCH_SIZE"], "WRITE_SIZE_KiB": avg["WRITE_SIZE"]},
+                   "correction": "FETCH_SIZE x2 (gfx950 wide coalesced reads), WRITE_SIZE x1; MI355X_MICROARCH.md section HBM"}
+            print("  HBM bytes per launch (corrected): read %.4g + write %.4g = %.4g" % (rd, wr, rd + wr))
+        if "TCC_HIT_sum" in avg and "TCC_MISS_sum" in avg:
+            out["l2_hit_rate"] = avg["TCC_HIT_sum"] / (avg["TCC_HIT_sum"] + avg["TCC_MISS_sum"])
+            print("  L2 hit rate %.4f" % out["l2_hit_rate"])
+        with open(os.path.join(root, "pmc_traffic.json"), "w") as fh:
+            json.dump(out, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()

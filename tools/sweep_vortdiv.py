@@ -21,6 +21,15 @@ import mi_fieldcalc_amd.synth as synth  # noqa: E402
 NX, NY, NLEV = (int(x) for x in os.environ.get("SWEEP_SHAPE", "1440,720,137").split(","))
 ROUNDS = int(os.environ.get("SWEEP_ROUNDS", "7"))
 INNER = int(os.environ.get("SWEEP_INNER", "5"))
+# yardstick kernels: name -> (variant, blocks); blocks 0 = one lane per 16 B
+YARD = {
+    "stream2 plain, 1 lane/16B": (0, 0),
+    "stream2 plain, 2048 blocks": (0, 2048),
+    "stream2 plain, 8192 blocks": (0, 8192),
+    "stream2 nt-store, 1 lane/16B": (1, 0),
+    "stream2 nt-ld+st, 1 lane/16B": (2, 0),
+    "stream2 nt-ld+st, 4096 blk": (2, 4096),
+}
 
 
 def main():
@@ -35,6 +44,7 @@ def main():
     alg = NX * NY * NLEV * 16 + 2 * NX * NY * 4
     results = {t: [] for t in tunes}
     copy_ms = []
+    yard_ms = {k: [] for k in YARD}
 
     def run(tune):
         os.environ["MIFC_VORTDIV_TUNE"] = tune
@@ -60,6 +70,15 @@ def main():
         e.record()
         torch.cuda.synchronize()
         copy_ms.append(s.elapsed_time(e) / INNER)
+        for key in YARD:
+            variant, blocks = YARD[key]
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(INNER):
+                ctx.bench_stream2(variant, blocks, rv, dg, du, dv)
+            e.record()
+            torch.cuda.synchronize()
+            yard_ms[key].append(s.elapsed_time(e) / INNER)
     print("shape %dx%dx%d, algorithmic bytes %.3f GB, %d rounds x %d launches" % (NX, NY, NLEV, alg / 1e9, ROUNDS, INNER))
     print("%-28s %9s %9s %9s %7s" % ("tuning", "med ms", "min ms", "GB/s(med)", "frac"))
     for t in tunes:
@@ -68,6 +87,9 @@ def main():
     cb = NX * NY * NLEV * 16
     med = float(np.median(copy_ms))
     print("%-28s %9.4f %9.4f %9.1f %7.4f   (2x torch copy_, same u+v -> 2 outputs bytes)" % ("d2d copy", med, float(np.min(copy_ms)), cb / med / 1e6, cb / med / 1e6 / 8000.0))
+    for key in YARD:
+        med = float(np.median(yard_ms[key]))
+        print("%-28s %9.4f %9.4f %9.1f %7.4f   (2-in/2-out float4 stream, no arithmetic)" % (key, med, float(np.min(yard_ms[key])), cb / med / 1e6, cb / med / 1e6 / 8000.0))
 
 
 if __name__ == "__main__":
