@@ -9,33 +9,40 @@
 // the store).
 //
 // Mapping to the hardware
-//   * work unit = one wavefront = 256 columns (64 lanes x float4) x R rows of
-//     one level.  The wave walks DOWN the rows keeping rows j-1, j, j+1 of u
+//   * work unit = one wavefront = 64 lanes x V float4 = 256*V columns x R rows
+//     of one level.  The wave walks DOWN the rows keeping rows j-1, j, j+1 of u
 //     and v in registers (row-sliding window): every u/v value is fetched
 //     once per band, halo overhead (R+2)/R on the reads only.
 //   * all global accesses are 16 B per lane, 1 KiB per wave-instruction,
 //     row-major and coalesced.  The window is a STATIC register ring of
 //     W = D+3 rows and the row loop is unrolled over the ring, so no loaded
-//     value is ever moved between registers and the compiler can keep D rows
-//     in flight with counted s_waitcnt vmcnt(N) (a rotating-variable window
-//     forces vmcnt(0) every iteration: moving an in-flight register needs its
-//     data).  Loads are branch-free: out-of-range lanes/rows read a clamped,
-//     valid address and only the STORES are predicated.
-//   * x neighbours (i-1, i+4) come from the adjacent lanes with one DPP
-//     wave-shift each (v_mov_b32_dpp wave_shr:1 / wave_shl:1) -- no LDS, no
-//     barrier; lane 0 and lane 63 take one scalar per row from the neighbouring
-//     wave-column (one dword load per field and row, lanes 0..62 share an
-//     address).
-//   * the four waves of a workgroup take FOUR CONSECUTIVE LEVELS of the same
-//     (band, wave-column) tile; the blockIdx -> tile map is XCD-aware (blocks
-//     are dealt round-robin over the 8 XCDs, block b runs sequence number
-//     (b % 8) * per_xcd + b / 8), so the levels of one tile meet in one L2 and
-//     xmapr / ymapr are fetched from HBM once per tile, not once per level.
+//     value is ever moved between registers and the compiler keeps D rows in
+//     flight with counted s_waitcnt vmcnt(N) (a rotating-variable window forces
+//     vmcnt(0) every iteration: moving an in-flight register needs its data).
+//     Loads are branch-free: out-of-range lanes/rows read a clamped, valid
+//     address and only the STORES are predicated.
+//   * x neighbours come from the adjacent lanes with one DPP wave-shift each
+//     (v_mov_b32_dpp wave_shr:1 / wave_shl:1) -- no LDS traffic, no barrier in
+//     the row loop; lane 0 and lane 63 take one scalar per row from the
+//     neighbouring wave-column.  Those two scalars cost two extra 128-byte
+//     lines per row, which is why V = 2 (512 columns per wave) is the default:
+//     it halves that overhead.
+//   * the waves of a workgroup take CONSECUTIVE LEVELS of the same (band,
+//     wave-column) tile; xmapr / ymapr of the tile are staged ONCE per
+//     workgroup in LDS (they do not depend on the level) and read from there
+//     with ds_read_b128 in the row loop.
+//   * blockIdx -> tile map is XCD-aware (blocks are dealt round-robin over the
+//     8 XCDs; block b runs sequence number (b % 8) * per_xcd + b / 8) and walks
+//     the batch in address order (level group, band, wave-column), so that the
+//     halo rows and edge lines a tile shares with its neighbours are fetched
+//     by the same XCD at about the same time.
 //   * undefined cells are counted per lane, reduced per wave (butterfly) and
 //     added with ONE atomic per wave to n_undefined[level]; the all-defined
 //     instantiation contains no test and no atomic at all.
 //   * no MFMA: 4 fp32 subtractions + 16 fp64-pipe ops per cell (6 cvt, 6 mul,
-//     2 add, 2 cvt back), the reference's double-promoted combine.
+//     2 add, 2 cvt back), the reference's double-promoted combine; measured to
+//     be fully hidden behind the memory traffic (a float-only build of the
+//     same kernel runs in the same time).
 #include "mifc_device.h"
 #include "mifc_kernels.h"
 
@@ -56,7 +63,6 @@ struct RowsParams
   int R;        // rows per band
   int nbands, nwc, nlev;
   int wpb;             // waves per workgroup (4, 8 or 16): that many levels side by side
-  int lpw;             // levels each wave walks through one after the other
   int uL, uB, uW;      // workgroup-unit counts along (level groups, bands, wave-columns)
   int n_logical;       // uL * uB * uW
   int per_xcd;         // ceil(n_logical / 8)
@@ -86,6 +92,13 @@ __device__ __forceinline__ float dpp_from_upper_lane(float keep_if_none, float x
                             __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
 }
 
+// NB: take the float BY VALUE.  __builtin_bit_cast applied directly to a vector
+// element expression (x.w) reads element 0 with this compiler.
+__device__ __forceinline__ float readlane_f(float x, int src_lane)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+}
+
 template <bool NT>
 __device__ __forceinline__ void store4(float* p, const v4f& v)
 {
@@ -95,24 +108,22 @@ __device__ __forceinline__ void store4(float* p, const v4f& v)
     *reinterpret_cast<v4f*>(p) = v;
 }
 
-template <bool NT>
 __device__ __forceinline__ v4f load4(const float* p)
 {
-  if (NT)
-    return __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
   return *reinterpret_cast<const v4f*>(p);
 }
 
+template <int V>
 struct RowRegs
 {
-  v4f u, v;
+  v4f u[V], v[V];
   float eu, ev; // lane 63: value east of the wave-column; other lanes: value west of it
 };
 
-// sequence number -> workgroup unit (l, b, w) along (levels, bands, wave-columns)
-//   order 1: address order -- level slowest, then band, wave-column fastest
-//   order 0: (wave-column, band) tiles, the levels of one tile consecutive
-//   order 2: (band, wave-column) tiles, the levels of one tile consecutive
+// sequence number -> workgroup unit (l, b, w) along (level groups, bands, wave-columns)
+//   order 1: address order -- level group slowest, then band, wave-column fastest
+//   order 0: (wave-column, band) tiles, the level groups of one tile consecutive
+//   order 2: (band, wave-column) tiles, the level groups of one tile consecutive
 __device__ __forceinline__ void decode_block(const RowsParams& P, int seq, int& l, int& b, int& w)
 {
   if (P.order == 1) {
@@ -134,10 +145,11 @@ __device__ __forceinline__ void decode_block(const RowsParams& P, int seq, int& 
   }
 }
 
-template <bool CHECK, bool WANT_V, bool WANT_D, int D, bool NT, bool NTL>
+template <bool CHECK, bool WANT_V, bool WANT_D, int D, bool NT, int V>
 __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
 {
-  constexpr int W = D + 3;                    // ring slots: rows r-2 (being refilled), r-1, r, r+1, r+2 .. r+D
+  constexpr int W = D + 3;    // ring slots: rows r-2 (being refilled), r-1, r, r+1, r+2 .. r+D
+  constexpr int WCOLS = 256 * V; // columns per wave
 
   // ---- which tile / level does this wave own -----------------------------
   const int wave = threadIdx.x >> 6;
@@ -148,18 +160,25 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
     return; // whole workgroup: nobody reaches the barrier below
   int lgroup, band, wc;
   decode_block(P, seq, lgroup, band, wc);
-  // this workgroup: levels [lev0, lev0 + wpb*lpw); wave w takes lev0 + w, lev0 + w + wpb, ...
-  const int lev0 = lgroup * (P.wpb * P.lpw);
+  // this workgroup: levels [lev0, lev0 + wpb), one per wave
+  const int lev0 = lgroup * P.wpb;
 
   const int nx = P.nx;
-  const int c0 = wc * 256 + lane * 4;
-  const bool active = c0 < nx;
-  const int c0c = active ? c0 : nx - 4; // clamped column for loads
-  int east_col = wc * 256 + 256;        // first column east of this wave-column (may be nx: wraps to the next row)
+  // Lane l owns V separate float4 per row: the q-th one at column
+  // wc*WCOLS + q*256 + 4*l, so every load/store instruction of the wave covers
+  // ONE contiguous KiB (64 lanes x 16 B).
+  int colq[V], colq_c[V];
+  bool actq[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    colq[q] = wc * WCOLS + q * 256 + lane * 4;
+    actq[q] = colq[q] < nx;
+    colq_c[q] = actq[q] ? colq[q] : nx - 4; // clamped column for loads
+  }
+  int east_col = wc * WCOLS + WCOLS; // first column east of this wave-column (may be nx: wraps to the next row)
   if (east_col > nx)
     east_col = nx;
-  const bool take_east_scalar = (c0 + 4 >= east_col); // my east neighbour is outside the wave-column
-  const int edge_col = (lane == 63) ? east_col : (wc * 256 - 1);
+  const int edge_col = (lane == 63) ? east_col : (wc * WCOLS - 1);
 
   const int jb = P.lo + band * P.R;                     // first local row of the band
   const int nr = (P.hi - jb < P.R) ? (P.hi - jb) : P.R; // rows in this band
@@ -167,26 +186,10 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
   const bool owns_top_edge = (P.j0 == 0);
   const bool owns_bottom_edge = (P.j0 + P.ny_local == P.nyg);
 
-  // ---- map factors of the tile: HBM/L2 -> LDS once per workgroup -------------
-  // xmapr/ymapr do not depend on the level; every wave of the workgroup and
-  // every level it walks through re-reads them from LDS (2 KiB per tile row).
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  v4f* lds_xm = reinterpret_cast<v4f*>(lds_raw);
-  v4f* lds_ym = lds_xm + P.R * 64;
-  for (int i = threadIdx.x; i < nr * 64; i += blockDim.x) {
-    const int row = i >> 6;
-    int col = wc * 256 + (i & 63) * 4;
-    col = col < nx ? col : nx - 4;
-    const long o = (long)(jb + row) * nx + col;
-    lds_xm[i] = load4<false>(P.xm + o);
-    lds_ym[i] = load4<false>(P.ym + o);
-  }
-  __syncthreads();
-
-  for (int li = 0; li < P.lpw; ++li) {
-  const int lev = lev0 + li * P.wpb + wave;
-  if (lev >= P.nlev)
-    break;
+  // the last level group may have fewer levels than waves: such a wave still
+  // helps staging the map factors, with its loads pointed at a valid level
+  const bool valid = (lev0 + wave) < P.nlev;
+  const int lev = valid ? (lev0 + wave) : (P.nlev - 1);
   const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
 
   const float* __restrict__ u = P.u + (size_t)lev * P.in_stride;
@@ -195,25 +198,52 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
   float* dv = WANT_D ? P.dv + (size_t)lev * P.out_stride : nullptr;
 
   // band-relative row rho in [-1, nr]; rows past the south halo are clamped to it
-  auto load_row = [&](int rho) -> RowRegs {
+  auto load_row = [&](int rho) -> RowRegs<V> {
     const int rc = rho > nr ? nr : rho;
     const long base = (long)(jb + rc) * nx;
-    RowRegs r;
-    r.u = load4<NTL>(u + base + c0c);
-    r.v = load4<NTL>(v + base + c0c);
+    RowRegs<V> r;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      r.u[q] = load4(u + base + colq_c[q]);
+      r.v[q] = load4(v + base + colq_c[q]);
+    }
+#ifdef MIFC_EXPERIMENT_NO_EDGE
+    r.eu = 0.f; // timing experiment only: wrong at wave-column boundaries
+    r.ev = 0.f;
+#else
     // x-neighbour scalar of the wave-column edge.  Only centre rows use it; the
     // clamp keeps the address inside the buffer for the rows that do not.
     long e = base + edge_col;
     e = e < P.idx_lo ? P.idx_lo : (e > P.idx_hi ? P.idx_hi : e);
     r.eu = u[e];
     r.ev = v[e];
+#endif
     return r;
   };
-  // ---- prologue: rows -1 .. D into ring slots (rho + 2) % W ----------------
-  RowRegs ring[W];
+  // ---- prologue: rows -1 .. D into ring slots (rho + 2) % W; issued before the
+  // map-factor staging so that both latencies overlap -------------------------
+  RowRegs<V> ring[W];
 #pragma unroll
   for (int rho = -1; rho <= D; ++rho)
     ring[(rho + 2) % W] = load_row(rho);
+
+  // ---- map factors of the tile: HBM/L2 -> LDS once per workgroup -------------
+  // xmapr/ymapr do not depend on the level: the waves of the workgroup (one
+  // level each) all read them from LDS (2*V KiB per tile row, memory order).
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  v4f* lds_xm = reinterpret_cast<v4f*>(lds_raw);
+  v4f* lds_ym = lds_xm + P.R * 64 * V;
+  for (int i = threadIdx.x; i < nr * 64 * V; i += blockDim.x) {
+    const int row = i / (64 * V);
+    int col = wc * WCOLS + (i - row * 64 * V) * 4;
+    col = col < nx ? col : nx - 4;
+    const long o = (long)(jb + row) * nx + col;
+    lds_xm[i] = load4(P.xm + o);
+    lds_ym[i] = load4(P.ym + o);
+  }
+  __syncthreads();
+  if (!valid)
+    return;
 
   unsigned int bad = 0;
 
@@ -226,81 +256,95 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
       // row r+1+D replaces row r-2, which nobody needs any more
       ring[s % W] = load_row(r + 1 + D);
 
-      const RowRegs& rp = ring[(s + 1) % W]; // row r-1
-      const RowRegs& rc = ring[(s + 2) % W]; // row r
-      const RowRegs& rn = ring[(s + 3) % W]; // row r+1
-      const v4f xm4 = lds_xm[r * 64 + lane], ym4 = lds_ym[r * 64 + lane];
+      const RowRegs<V>& rp = ring[(s + 1) % W]; // row r-1
+      const RowRegs<V>& rc = ring[(s + 2) % W]; // row r
+      const RowRegs<V>& rn = ring[(s + 3) % W]; // row r+1
 
-      // ---- x neighbours of the centre row from the adjacent lanes ----------
-      const float east_u = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rc.eu), 63));
-      const float east_v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rc.ev), 63));
-      float uW = dpp_from_lower_lane(rc.eu, rc.u.w); // lane 0 keeps its own west scalar
-      float vW = dpp_from_lower_lane(rc.ev, rc.v.w);
-      float uE = dpp_from_upper_lane(rc.eu, rc.u.x); // lane 63 keeps its own east scalar
-      float vE = dpp_from_upper_lane(rc.ev, rc.v.x);
-      if (take_east_scalar) {
-        uE = east_u;
-        vE = east_v;
-      }
+      const float east_u = readlane_f(rc.eu, 63);
+      const float east_v = readlane_f(rc.ev, 63);
+      const int jl = jb + r;
+      const int j = P.j0 + jl;
 
-      const float uc[6] = {uW, rc.u.x, rc.u.y, rc.u.z, rc.u.w, uE};
-      const float vc[6] = {vW, rc.v.x, rc.v.y, rc.v.z, rc.v.w, vE};
-      const float us[4] = {rp.u.x, rp.u.y, rp.u.z, rp.u.w}; // row j-1
-      const float un[4] = {rn.u.x, rn.u.y, rn.u.z, rn.u.w}; // row j+1
-      const float vs[4] = {rp.v.x, rp.v.y, rp.v.z, rp.v.w};
-      const float vn[4] = {rn.v.x, rn.v.y, rn.v.z, rn.v.w};
-      const float xm[4] = {xm4.x, xm4.y, xm4.z, xm4.w};
-      const float ym[4] = {ym4.x, ym4.y, ym4.z, ym4.w};
-      float zv[4] = {0.f, 0.f, 0.f, 0.f}, zd[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float vw = vc[k], ve = vc[k + 2], uw = uc[k], ue = uc[k + 2];
-        bool ok = true;
-        if (CHECK)
-          ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef)); // :1861, :1927
-        if (WANT_V)
-          zv[k] = ok ? f_relvort(xm[k], ym[k], ve - vw, un[k] - us[k]) : undef;
-        if (WANT_D)
-          zd[k] = ok ? f_diverg(xm[k], ym[k], ue - uw, vn[k] - vs[k]) : undef;
-        if (CHECK && !ok && active)
-          bad += 1;
-      }
-      // ---- fillEdges, column part (:65-68), folded into the store ----------
-      if (c0 == 0) {
-        zv[0] = zv[1];
-        zd[0] = zd[1];
-      }
-      if (c0 + 4 == nx) {
-        zv[3] = zv[2];
-        zd[3] = zd[2];
-      }
-      if (active) {
-        const int jl = jb + r;
-        const long o = (long)jl * nx + c0;
-        const int j = P.j0 + jl;
-        if (WANT_V) {
-          v4f z4;
-          z4.x = zv[0];
-          z4.y = zv[1];
-          z4.z = zv[2];
-          z4.w = zv[3];
-          store4<NT>(rv + o, z4);
-          if (j == 1 && owns_top_edge) // row part of fillEdges (:70-73)
-            store4<NT>(rv + o - nx, z4);
-          if (j == P.nyg - 2 && owns_bottom_edge)
-            store4<NT>(rv + o + nx, z4);
+      for (int q = 0; q < V; ++q) {
+        // ---- x neighbours of the centre row: adjacent lanes by DPP wave shift;
+        // lane 0 / lane 63 continue into the neighbouring 1-KiB segment of this
+        // wave (readlane) or take the wave-column edge scalar
+        float uW = dpp_from_lower_lane(rc.eu, rc.u[q].w); // lane 0 keeps the west scalar
+        float vW = dpp_from_lower_lane(rc.ev, rc.v[q].w);
+        float uE = dpp_from_upper_lane(rc.eu, rc.u[q].x); // lane 63 keeps the east scalar
+        float vE = dpp_from_upper_lane(rc.ev, rc.v[q].x);
+        if (q > 0) { // lane 0 continues into the last lane of the previous segment
+          const float tu = readlane_f(rc.u[q > 0 ? q - 1 : 0].w, 63);
+          const float tv = readlane_f(rc.v[q > 0 ? q - 1 : 0].w, 63);
+          uW = (lane == 0) ? tu : uW;
+          vW = (lane == 0) ? tv : vW;
         }
-        if (WANT_D) {
-          v4f d4;
-          d4.x = zd[0];
-          d4.y = zd[1];
-          d4.z = zd[2];
-          d4.w = zd[3];
-          store4<NT>(dv + o, d4);
-          if (j == 1 && owns_top_edge)
-            store4<NT>(dv + o - nx, d4);
-          if (j == P.nyg - 2 && owns_bottom_edge)
-            store4<NT>(dv + o + nx, d4);
+        if (q < V - 1) { // lane 63 continues into the first lane of the next segment
+          const float tu = readlane_f(rc.u[q < V - 1 ? q + 1 : q].x, 0);
+          const float tv = readlane_f(rc.v[q < V - 1 ? q + 1 : q].x, 0);
+          uE = (lane == 63) ? tu : uE;
+          vE = (lane == 63) ? tv : vE;
+        }
+        if (colq[q] + 4 >= east_col) { // my east neighbour is outside the wave-column
+          uE = east_u;
+          vE = east_v;
+        }
+        const v4f xm4 = lds_xm[(r * V + q) * 64 + lane], ym4 = lds_ym[(r * V + q) * 64 + lane];
+        const float uc[6] = {uW, rc.u[q].x, rc.u[q].y, rc.u[q].z, rc.u[q].w, uE};
+        const float vc[6] = {vW, rc.v[q].x, rc.v[q].y, rc.v[q].z, rc.v[q].w, vE};
+        float zv[4], zd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float vw = vc[k], ve = vc[k + 2], uw = uc[k], ue = uc[k + 2];
+          const float us = rp.u[q][k], un = rn.u[q][k], vs = rp.v[q][k], vn = rn.v[q][k]; // rows j-1 / j+1
+          bool ok = true;
+          if (CHECK)
+            ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us, undef) && is_def(un, undef)); // :1861, :1927
+          zv[k] = 0.f;
+          zd[k] = 0.f;
+          if (WANT_V)
+            zv[k] = ok ? f_relvort(xm4[k], ym4[k], ve - vw, un - us) : undef;
+          if (WANT_D)
+            zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, vn - vs) : undef;
+          if (CHECK && !ok && actq[q])
+            bad += 1;
+        }
+        // ---- fillEdges, column part (:65-68), folded into the store ----------
+        if (colq[q] == 0) {
+          zv[0] = zv[1];
+          zd[0] = zd[1];
+        }
+        if (colq[q] + 4 == nx) {
+          zv[3] = zv[2];
+          zd[3] = zd[2];
+        }
+        if (actq[q]) {
+          const long o = (long)jl * nx + colq[q];
+          if (WANT_V) {
+            v4f z4;
+            z4.x = zv[0];
+            z4.y = zv[1];
+            z4.z = zv[2];
+            z4.w = zv[3];
+            store4<NT>(rv + o, z4);
+            if (j == 1 && owns_top_edge) // row part of fillEdges (:70-73)
+              store4<NT>(rv + o - nx, z4);
+            if (j == P.nyg - 2 && owns_bottom_edge)
+              store4<NT>(rv + o + nx, z4);
+          }
+          if (WANT_D) {
+            v4f d4;
+            d4.x = zd[0];
+            d4.y = zd[1];
+            d4.z = zd[2];
+            d4.w = zd[3];
+            store4<NT>(dv + o, d4);
+            if (j == 1 && owns_top_edge)
+              store4<NT>(dv + o - nx, d4);
+            if (j == P.nyg - 2 && owns_bottom_edge)
+              store4<NT>(dv + o + nx, d4);
+          }
         }
       }
     }
@@ -308,7 +352,6 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
 level_done:
   if (CHECK && P.n_undefined)
     wave_count_add(P.n_undefined + lev, bad);
-  } // levels of this wave
 }
 
 struct Tuning
@@ -316,11 +359,10 @@ struct Tuning
   int R;     // rows per band
   int D;     // rows kept in flight beyond the 3-row window (0..2)
   int NT;    // nontemporal stores
-  int NTL;   // nontemporal loads of u, v
+  int V;     // float4 per lane and row (1 or 2): the wave covers 256*V columns
   int ORDER; // block order, see decode_block()
   int XCD;   // XCD-aware blockIdx remap
   int WPB;   // waves per workgroup: 4, 8 or 16 (levels side by side)
-  int LPW;   // levels each wave walks through one after the other
 };
 
 int tune_value(const char* s, const char* key, int dflt)
@@ -337,53 +379,56 @@ int tune_value(const char* s, const char* key, int dflt)
   return dflt;
 }
 
-Tuning current_tuning()
+Tuning current_tuning(int nx)
 {
-  Tuning t = {8, 1, 1, 0, 1, 1, 4, 1};
-  // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,NTL=0,ORDER=1,XCD=1,WPB=4,LPW=1" -- used by the sweep tool and the tests
+  Tuning t = {8, 1, 1, 2, 1, 1, 8};
+  // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,V=2,ORDER=1,XCD=1,WPB=8" -- used by the sweep tool and the tests
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     t.R = tune_value(s, "R", t.R);
     t.D = tune_value(s, "D", t.D);
     t.NT = tune_value(s, "NT", t.NT);
-    t.NTL = tune_value(s, "NTL", t.NTL);
+    t.V = tune_value(s, "V", t.V);
     t.ORDER = tune_value(s, "ORDER", t.ORDER);
     t.XCD = tune_value(s, "XCD", t.XCD);
     t.WPB = tune_value(s, "WPB", t.WPB);
-    t.LPW = tune_value(s, "LPW", t.LPW);
   }
   if (t.WPB != 4 && t.WPB != 8 && t.WPB != 16)
     t.WPB = 4;
-  if (t.LPW < 1)
-    t.LPW = 1;
+  if (t.V != 1 && t.V != 2)
+    t.V = 2;
+  if (nx <= 256)
+    t.V = 1; // a second 256-column segment would be empty
   if (t.R < 1)
     t.R = 1;
-  if (t.R > 32)
-    t.R = 32; // map-factor tile in LDS: 2 KiB per row, 64 KiB at most
+  const int rmax = 32 / t.V; // map-factor tile in LDS: 2*V KiB per row, 64 KiB at most
+  if (t.R > rmax)
+    t.R = rmax;
   if (t.D < 0)
     t.D = 0;
   if (t.D > 2)
     t.D = 2;
+  if (t.V == 2 && t.D > 1)
+    t.D = 1; // the 5-row ring of 512-column rows does not fit 128 VGPRs without spilling
   return t;
+}
+
+template <bool CHECK, bool WV, bool WD, int D, bool NT>
+void launch_v(const RowsParams& rp, const Tuning& t, int grid, hipStream_t stream)
+{
+  const size_t lds = (size_t)rp.R * 2048 * t.V;
+  if (t.V == 2)
+    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, D, NT, 2>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
+  else
+    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, D, NT, 1>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
 }
 
 template <bool CHECK, bool WV, bool WD, int D>
 void launch_nt(const RowsParams& rp, const Tuning& t, int grid, hipStream_t stream)
 {
-  const int sel = (t.NT ? 1 : 0) | (t.NTL ? 2 : 0);
-  switch (sel) {
-  case 0:
-    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, D, false, false>), dim3(grid), dim3(64 * t.WPB), (size_t)rp.R * 2048, stream, rp);
-    break;
-  case 1:
-    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, D, true, false>), dim3(grid), dim3(64 * t.WPB), (size_t)rp.R * 2048, stream, rp);
-    break;
-  case 2:
-    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, D, false, true>), dim3(grid), dim3(64 * t.WPB), (size_t)rp.R * 2048, stream, rp);
-    break;
-  default:
-    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, D, true, true>), dim3(grid), dim3(64 * t.WPB), (size_t)rp.R * 2048, stream, rp);
-    break;
-  }
+  if (t.NT)
+    launch_v<CHECK, WV, WD, D, true>(rp, t, grid, stream);
+  else
+    launch_v<CHECK, WV, WD, D, false>(rp, t, grid, stream);
 }
 
 template <bool CHECK, bool WV, bool WD>
@@ -450,7 +495,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   if (std::getenv("MIFC_FORCE_CELL_KERNEL"))
     return hipSuccess;
 
-  const Tuning t = current_tuning();
+  const Tuning t = current_tuning(nx);
   RowsParams rp;
   rp.nx = nx;
   rp.nyg = prm.ny_global;
@@ -471,11 +516,10 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.idx_hi = (long)nx * (prm.ny_local + (has_south_halo ? 1 : 0)) - 1;
   rp.R = t.R;
   rp.nbands = (rp.hi - rp.lo + t.R - 1) / t.R;
-  rp.nwc = (nx + 255) / 256;
+  rp.nwc = (nx + 256 * t.V - 1) / (256 * t.V);
   rp.nlev = prm.nlev;
   rp.wpb = t.WPB;
-  rp.lpw = t.LPW;
-  rp.uL = (prm.nlev + t.WPB * t.LPW - 1) / (t.WPB * t.LPW);
+  rp.uL = (prm.nlev + t.WPB - 1) / t.WPB;
   rp.uB = rp.nbands;
   rp.uW = rp.nwc;
   const long n_logical = (long)rp.uL * rp.uB * rp.uW;
