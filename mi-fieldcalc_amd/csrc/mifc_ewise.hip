@@ -16,7 +16,7 @@ namespace {
 // defined (r holds the value); false => cell := undef and is counted.
 // `keep` is set for the one case where the reference leaves a defined cell
 // unwritten (hleveltemp with compute outside 1..5, FieldCalculations.cc:1080-1090).
-__device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* tab, float a, float b, float c, float& r, bool& keep)
+__device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* tab, const PowTables& PT, float a, float b, float c, float& r, bool& keep)
 {
   const bool all = P.all_defined != 0;
   const float undef = P.undef;
@@ -40,7 +40,7 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
       if (!(all || (is_def(a, undef) && is_def(c, undef)))) // :1077, :1334
         return false;
       p = (P.psrc == PS_HYBRID) ? (P.alevel + P.blevel * c) : c; // :303
-      pidcp = pidcp_of(p);
+      pidcp = pidcp_of(PT, p);
       pi = pidcp * MIFC_K_CP;
     }
     switch (P.compute) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
         p = (P.kind == HUM_RH_TD && !P.from_theta) ? 0.0f : (P.alevel + P.blevel * c); // need_p :1182,:1188
       else
         p = c;
-      tk = P.from_theta ? a * pidcp_of(p) : a;
+      tk = P.from_theta ? a * pidcp_of(PT, p) : a;
     }
     switch (P.kind) {
     case HUM_Q_RH:
@@ -118,7 +118,9 @@ template <bool VEC4>
 __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
 {
   __shared__ float s_ewt[MIFC_N_EWT];
+  __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
   ewt_table_init(s_ewt);
+  const PowTables PT = pow_tables_init(s_pow);
 
   const bool use1 = P.in1 != nullptr;
   const bool use2 = P.in2 != nullptr;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
       for (int k = 0; k < 4; ++k) {
         float r = 0.f;
         bool keep;
-        if (ewise_point(P, s_ewt, av[k], bv[k], cv[k], r, keep)) {
+        if (ewise_point(P, s_ewt, PT, av[k], bv[k], cv[k], r, keep)) {
           if (!keep)
             ov[k] = r;
         } else {
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
       const float c = use2 ? P.in2[i] : 0.f;
       float r = 0.f;
       bool keep;
-      if (ewise_point(P, s_ewt, a, b, c, r, keep)) {
+      if (ewise_point(P, s_ewt, PT, a, b, c, r, keep)) {
         if (!keep)
           P.out[i] = r;
       } else {
@@ -224,11 +226,25 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
 // three outputs (12 B)  => 28 B/cell + ps.  p = a + b*ps and powf(p*p0inv,
 // kappa) are evaluated once per cell and shared by rh (needs p) and theta
 // (needs pidcp).  grid.y = level; each lane owns 4 consecutive cells.
+// outputs are written once and never re-read by this library: nontemporal store
+__device__ __forceinline__ void store4_stream(float* p, float a, float b, float c, float d)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f t;
+  t.x = a;
+  t.y = b;
+  t.z = c;
+  t.w = d;
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+
 template <bool CHECK>
 __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams P)
 {
   __shared__ float s_ewt[MIFC_N_EWT];
+  __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
   ewt_table_init(s_ewt);
+  const PowTables PT = pow_tables_init(s_pow);
 
   const int lev = blockIdx.y;
   const size_t base = (size_t)lev * (size_t)P.n;
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
           bad_ff += 1;
         }
       }
-      *reinterpret_cast<float4*>(P.ff + o) = make_float4(r[0], r[1], r[2], r[3]);
+      store4_stream(P.ff + o, r[0], r[1], r[2], r[3]);
     }
     if (want_rh || want_th) {
       const float4 t4 = *reinterpret_cast<const float4*>(P.t + o);
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
         const float p = a + b * ss[k]; // p_hlevel :303
         if (want_th) {              // hleveltemp compute 3, :1077-1085
           if (thermo_all || (is_def(tt[k], undef) && is_def(ss[k], undef))) {
-            rt[k] = tt[k] / pidcp_of(p);
+            rt[k] = tt[k] / pidcp_of(PT, p);
           } else {
             rt[k] = undef;
             bad_th += 1;
@@ -286,9 +302,9 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
         }
       }
       if (want_rh)
-        *reinterpret_cast<float4*>(P.rh + o) = make_float4(rr[0], rr[1], rr[2], rr[3]);
+        store4_stream(P.rh + o, rr[0], rr[1], rr[2], rr[3]);
       if (want_th)
-        *reinterpret_cast<float4*>(P.theta + o) = make_float4(rt[0], rt[1], rt[2], rt[3]);
+        store4_stream(P.theta + o, rt[0], rt[1], rt[2], rt[3]);
     }
   }
   // The ewt table can reject a cell even when the inputs are ALL_DEFINED, so

@@ -68,6 +68,7 @@ struct RowsParams
   int per_xcd;         // ceil(n_logical / 8)
   int order;           // block sequence -> unit order, see decode_block()
   int xcd_remap;       // 1: sequence = (b % 8) * per_xcd + b / 8
+  int zigzag;          // 1: odd bands walk upwards
   long idx_lo, idx_hi; // valid flat element range relative to owned row 0 (for clamped scalar loads)
   const float *u, *v, *xm, *ym;
   float *rv, *dv;
@@ -197,10 +198,17 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
   float* rv = WANT_V ? P.rv + (size_t)lev * P.out_stride : nullptr;
   float* dv = WANT_D ? P.dv + (size_t)lev * P.out_stride : nullptr;
 
-  // band-relative row rho in [-1, nr]; rows past the south halo are clamped to it
-  auto load_row = [&](int rho) -> RowRegs<V> {
-    const int rc = rho > nr ? nr : rho;
-    const long base = (long)(jb + rc) * nx;
+  // Bands alternate their walking direction: even bands go down, odd bands go
+  // up.  The halo rows a band shares with its neighbours are then loaded by
+  // both at the SAME phase of their walk (both at the start, or both at the
+  // end), i.e. at about the same time on the same XCD, and the second fetch
+  // hits L2 instead of going back to HBM.
+  const bool up = (P.zigzag != 0) && ((band & 1) != 0);
+  // step t in [-1, nr] of the walk -> local row; steps past the far halo are clamped to it
+  auto load_row = [&](int t) -> RowRegs<V> {
+    const int tc = t > nr ? nr : t;
+    const int rowl = up ? (nr - 1 - tc) : tc;
+    const long base = (long)(jb + rowl) * nx;
     RowRegs<V> r;
 #pragma unroll
     for (int q = 0; q < V; ++q) {
@@ -256,13 +264,18 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
       // row r+1+D replaces row r-2, which nobody needs any more
       ring[s % W] = load_row(r + 1 + D);
 
-      const RowRegs<V>& rp = ring[(s + 1) % W]; // row r-1
-      const RowRegs<V>& rc = ring[(s + 2) % W]; // row r
-      const RowRegs<V>& rn = ring[(s + 3) % W]; // row r+1
+      // previous / current / next step of the walk.  Walking down, "previous"
+      // is row j-1 and "next" row j+1; walking up it is the other way round, so
+      // the y-differences are formed in both orders and selected (a - b and
+      // -(b - a) would differ in the sign of an exact zero)
+      const RowRegs<V>& rp = ring[(s + 1) % W];
+      const RowRegs<V>& rc = ring[(s + 2) % W];
+      const RowRegs<V>& rn = ring[(s + 3) % W];
 
       const float east_u = readlane_f(rc.eu, 63);
       const float east_v = readlane_f(rc.ev, 63);
-      const int jl = jb + r;
+      const int rl = up ? (nr - 1 - r) : r; // local row inside the band
+      const int jl = jb + rl;
       const int j = P.j0 + jl;
 
 #pragma unroll
@@ -290,23 +303,25 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
           uE = east_u;
           vE = east_v;
         }
-        const v4f xm4 = lds_xm[(r * V + q) * 64 + lane], ym4 = lds_ym[(r * V + q) * 64 + lane];
+        const v4f xm4 = lds_xm[(rl * V + q) * 64 + lane], ym4 = lds_ym[(rl * V + q) * 64 + lane];
         const float uc[6] = {uW, rc.u[q].x, rc.u[q].y, rc.u[q].z, rc.u[q].w, uE};
         const float vc[6] = {vW, rc.v[q].x, rc.v[q].y, rc.v[q].z, rc.v[q].w, vE};
         float zv[4], zd[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float vw = vc[k], ve = vc[k + 2], uw = uc[k], ue = uc[k + 2];
-          const float us = rp.u[q][k], un = rn.u[q][k], vs = rp.v[q][k], vn = rn.v[q][k]; // rows j-1 / j+1
+          const float ua = rp.u[q][k], ub = rn.u[q][k], va = rp.v[q][k], vb = rn.v[q][k]; // rows j-1 / j+1 in walk order
           bool ok = true;
           if (CHECK)
-            ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us, undef) && is_def(un, undef)); // :1861, :1927
+            ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(ua, undef) && is_def(ub, undef)); // :1861, :1927
+          const float dudy = up ? (ua - ub) : (ub - ua); // u[i+nx] - u[i-nx]
+          const float dvdy = up ? (va - vb) : (vb - va);
           zv[k] = 0.f;
           zd[k] = 0.f;
           if (WANT_V)
-            zv[k] = ok ? f_relvort(xm4[k], ym4[k], ve - vw, un - us) : undef;
+            zv[k] = ok ? f_relvort(xm4[k], ym4[k], ve - vw, dudy) : undef;
           if (WANT_D)
-            zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, vn - vs) : undef;
+            zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, dvdy) : undef;
           if (CHECK && !ok && actq[q])
             bad += 1;
         }
@@ -363,6 +378,7 @@ struct Tuning
   int ORDER; // block order, see decode_block()
   int XCD;   // XCD-aware blockIdx remap
   int WPB;   // waves per workgroup: 4, 8 or 16 (levels side by side)
+  int ZZ;    // odd bands walk upwards (halo rows meet in L2)
 };
 
 int tune_value(const char* s, const char* key, int dflt)
@@ -381,7 +397,7 @@ int tune_value(const char* s, const char* key, int dflt)
 
 Tuning current_tuning(int nx)
 {
-  Tuning t = {8, 1, 1, 2, 1, 1, 8};
+  Tuning t = {8, 1, 1, 2, 1, 1, 8, 1};
   // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,V=2,ORDER=1,XCD=1,WPB=8" -- used by the sweep tool and the tests
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     t.R = tune_value(s, "R", t.R);
@@ -391,9 +407,10 @@ Tuning current_tuning(int nx)
     t.ORDER = tune_value(s, "ORDER", t.ORDER);
     t.XCD = tune_value(s, "XCD", t.XCD);
     t.WPB = tune_value(s, "WPB", t.WPB);
+    t.ZZ = tune_value(s, "ZZ", t.ZZ);
   }
-  if (t.WPB != 4 && t.WPB != 8 && t.WPB != 16)
-    t.WPB = 4;
+  if (t.WPB != 1 && t.WPB != 2 && t.WPB != 4 && t.WPB != 8 && t.WPB != 16)
+    t.WPB = 8;
   if (t.V != 1 && t.V != 2)
     t.V = 2;
   if (nx <= 256)
@@ -495,7 +512,9 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   if (std::getenv("MIFC_FORCE_CELL_KERNEL"))
     return hipSuccess;
 
-  const Tuning t = current_tuning(nx);
+  Tuning t = current_tuning(nx);
+  while (t.WPB > 1 && t.WPB / 2 >= prm.nlev)
+    t.WPB /= 2; // fewer levels than waves: do not launch waves that only stage map factors
   RowsParams rp;
   rp.nx = nx;
   rp.nyg = prm.ny_global;
@@ -529,6 +548,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.per_xcd = (rp.n_logical + 7) / 8;
   rp.order = t.ORDER;
   rp.xcd_remap = t.XCD;
+  rp.zigzag = t.ZZ;
   rp.u = prm.f0;
   rp.v = prm.f1;
   rp.xm = prm.xmapr;
