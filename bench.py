@@ -170,11 +170,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MIFC_BENCH_BACKEND=gloo is a self-test aid only (rehearsing the N>1 control flow on a
+    # one-GPU box, ranks sharing cuda:0); the driver's runs use nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("MIFC_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- this rank's batch: one ensemble member = 137 levels, generated in HBM
     xm, ym, _ = synth.grid_maps(NX, NY)
@@ -185,7 +193,7 @@ def main():
     flags = np.full(NLEV, fc.ALL_DEFINED, np.int32)
     counts = torch.zeros(NLEV, dtype=torch.int64, device=dev)
 
-    ctx = fc.Context(local_rank)
+    ctx = fc.Context(dev_index)
     ctx.use_torch_stream()
 
     def step(check=False):
@@ -221,7 +229,7 @@ def main():
     torch.cuda.synchronize()
     wall, kern_ms = timed(args.steps)
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 

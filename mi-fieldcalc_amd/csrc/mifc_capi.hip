@@ -912,30 +912,44 @@ static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u,
   P.rh = rh;
   P.theta = theta;
   P.undef = undef;
-  if (!pinned_acquire(c))
-    return 0;
   bool every_all = true;
-  unsigned char* hf = pinned_flags(c);
-  for (int l = 0; l < nlev; ++l) {
-    const bool w = !ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
-    const bool th = !(rh || theta) || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
-    hf[l] = w ? 1 : 0;
-    hf[c->cap_lev + l] = th ? 1 : 0;
-    every_all = every_all && w && th;
+  if (nlev <= 8) {
+    // small batch: per-level scalars travel in the kernel arguments
+    P.n_inline = 1;
+    for (int l = 0; l < nlev; ++l) {
+      const bool w = !ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
+      const bool th = !(rh || theta) || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
+      P.wind_inline[l] = w ? 1 : 0;
+      P.thermo_inline[l] = th ? 1 : 0;
+      P.a_inline[l] = (rh || theta) ? alevel[l] : 0.f;
+      P.b_inline[l] = (rh || theta) ? blevel[l] : 0.f;
+      every_all = every_all && w && th;
+    }
+  } else {
+    if (!pinned_acquire(c))
+      return 0;
+    unsigned char* hf = pinned_flags(c);
+    for (int l = 0; l < nlev; ++l) {
+      const bool w = !ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
+      const bool th = !(rh || theta) || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
+      hf[l] = w ? 1 : 0;
+      hf[c->cap_lev + l] = th ? 1 : 0;
+      every_all = every_all && w && th;
+    }
+    float* hab = pinned_ab(c);
+    for (int l = 0; l < nlev; ++l) {
+      hab[l] = (rh || theta) ? alevel[l] : 0.f;
+      hab[c->cap_lev + l] = (rh || theta) ? blevel[l] : 0.f;
+    }
+    MIFC_HIP(c, hipMemcpyAsync(c->d_ab, hab, 2 * c->cap_lev * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    MIFC_HIP(c, hipMemcpyAsync(c->d_flags, hf, 2 * c->cap_lev, hipMemcpyHostToDevice, c->stream));
+    if (!pinned_release(c))
+      return 0;
+    P.alevel = c->d_ab;
+    P.blevel = c->d_ab + c->cap_lev;
+    P.wind_all_defined = c->d_flags;
+    P.thermo_all_defined = c->d_flags + c->cap_lev;
   }
-  float* hab = pinned_ab(c);
-  for (int l = 0; l < nlev; ++l) {
-    hab[l] = (rh || theta) ? alevel[l] : 0.f;
-    hab[c->cap_lev + l] = (rh || theta) ? blevel[l] : 0.f;
-  }
-  MIFC_HIP(c, hipMemcpyAsync(c->d_ab, hab, 2 * c->cap_lev * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  MIFC_HIP(c, hipMemcpyAsync(c->d_flags, hf, 2 * c->cap_lev, hipMemcpyHostToDevice, c->stream));
-  if (!pinned_release(c))
-    return 0;
-  P.alevel = c->d_ab;
-  P.blevel = c->d_ab + c->cap_lev;
-  P.wind_all_defined = c->d_flags;
-  P.thermo_all_defined = c->d_flags + c->cap_lev;
   P.every_level_all_defined = every_all ? 1 : 0;
   P.n_undefined = counts_dev;
   MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 3 * sizeof(u64) * (size_t)nlev, c->stream));

@@ -249,9 +249,10 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
   const int lev = blockIdx.y;
   const size_t base = (size_t)lev * (size_t)P.n;
   const bool want_ff = P.ff != nullptr, want_rh = P.rh != nullptr, want_th = P.theta != nullptr;
-  const bool wind_all = CHECK ? (P.wind_all_defined[lev] != 0) : true;
-  const bool thermo_all = CHECK ? (P.thermo_all_defined[lev] != 0) : true;
-  const float a = P.alevel[lev], b = P.blevel[lev];
+  const bool wind_all = CHECK ? ((P.n_inline ? P.wind_inline[lev] : P.wind_all_defined[lev]) != 0) : true;
+  const bool thermo_all = CHECK ? ((P.n_inline ? P.thermo_inline[lev] : P.thermo_all_defined[lev]) != 0) : true;
+  const float a = P.n_inline ? P.a_inline[lev] : P.alevel[lev];
+  const float b = P.n_inline ? P.b_inline[lev] : P.blevel[lev];
   const float undef = P.undef;
   unsigned int bad_ff = 0, bad_rh = 0, bad_th = 0;
 
@@ -342,8 +343,8 @@ hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream)
     p.ff = prm.ff ? prm.ff + off : nullptr;
     p.rh = prm.rh ? prm.rh + off : nullptr;
     p.theta = prm.theta ? prm.theta + off : nullptr;
-    p.alevel = prm.alevel + l0;
-    p.blevel = prm.blevel + l0;
+    p.alevel = prm.alevel ? prm.alevel + l0 : nullptr;
+    p.blevel = prm.blevel ? prm.blevel + l0 : nullptr;
     p.wind_all_defined = prm.wind_all_defined ? prm.wind_all_defined + l0 : nullptr;
     p.thermo_all_defined = prm.thermo_all_defined ? prm.thermo_all_defined + l0 : nullptr;
     p.n_undefined = prm.n_undefined ? prm.n_undefined + l0 : nullptr;

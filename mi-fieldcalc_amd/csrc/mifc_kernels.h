@@ -63,6 +63,11 @@ struct DerivedParams
   int every_level_all_defined;             // host hint: skip all tests and counting
   float undef;
   u64* n_undefined; // device u64[3*nlev]: ff | rh | theta
+  // small batches (nlev <= 8, e.g. the single level of BASELINE.json config 2)
+  // carry the per-level scalars in the kernel arguments: no upload before the launch
+  int n_inline; // != 0: use the arrays below instead of the device arrays above
+  float a_inline[8], b_inline[8];
+  unsigned char wind_inline[8], thermo_inline[8];
 };
 hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream);
 
