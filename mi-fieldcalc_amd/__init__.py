@@ -251,6 +251,33 @@ class Context:
         outs = tuple(o if (o is None or _is_torch(o)) else a.keep for o, a in ((rvort, ar), (diverg, ad)))
         return outs, flags
 
+    OPS = {"relvort": 0, "absvort": 1, "divergence": 2, "vortdiv": 3, "gradient1": 4, "gradient2": 5, "gradient3": 6, "gradient4": 7,
+           "plevelgwind_xcomp": 8, "plevelgwind_ycomp": 9, "plevelgvort": 10, "ilevelgwind": 11}
+
+    def stencil_levels(self, op, f0, f1, xmapr, ymapr, fcoriolis=None, fdefined=None, undef=UNDEF, out0=None, out1=None):
+        """Any stencil operator (name from Context.OPS) over f0/f1 of shape (nlev, ny, nx).
+        Returns ((out0, out1-or-None), flags) or None."""
+        code = self.OPS[op]
+        a0, a1 = _Arg(f0), _Arg(f1, allow_none=True)
+        ax, ay, af = _Arg(xmapr, allow_none=True), _Arg(ymapr, allow_none=True), _Arg(fcoriolis, allow_none=True)
+        nlev, ny, nx = a0.shape
+        two = code in (3, 11)
+        if out0 is None:
+            out0 = _empty_like(f0)
+        if two and out1 is None:
+            out1 = _empty_like(f0)
+        o0, o1 = _Arg(out0), _Arg(out1 if two else None, allow_none=True)
+        mk = _memkind([a0, a1, ax, ay, af, o0, o1])
+        self._bind_stream(mk)
+        flags = np.full(nlev, SOME_DEFINED, dtype=np.int32) if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
+        rc = self._call("mifc_stencil_levels", [code, nx, ny, nlev, a0.addr, a1.addr, ax.addr, ay.addr, af.addr, o0.addr, o1.addr,
+                                                flags.ctypes.data, float(undef), mk])
+        if not rc:
+            return None
+        r0 = out0 if _is_torch(out0) else o0.keep
+        r1 = None if not two else (out1 if _is_torch(out1) else o1.keep)
+        return (r0, r1), flags
+
     def vortdiv_levels_enqueue(self, u, v, xmapr, ymapr, rvort, diverg, fdefined=None, undef=UNDEF, n_undefined=None):
         """Asynchronous form on device tensors; n_undefined: int64 CUDA tensor[nlev] or None."""
         au, av, ax, ay = _Arg(u), _Arg(v), _Arg(xmapr), _Arg(ymapr)

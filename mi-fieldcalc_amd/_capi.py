@@ -61,6 +61,7 @@ SIGNATURES = {
     "mifc_ilevelgwind": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     # batched
     "mifc_vortdiv_levels": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_stencil_levels": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_vortdiv_levels_enqueue": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "pu"]),
     "mifc_hlevel_derived_levels": (
         "i",

@@ -824,6 +824,22 @@ int mifc_vortdiv_levels(mifc_ctx* c, int nx, int ny, int nlev, const float* u, c
   return run_stencil(c, sc, fdefined, undef, memkind);
 }
 
+int mifc_stencil_levels(mifc_ctx* c, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* xmapr, const float* ymapr,
+                        const float* fcoriolis, float* out0, float* out1, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (op < mifc::ST_RELVORT || op > mifc::ST_IGWIND || !f0 || !out0)
+    return 0;
+  const bool wind = (op <= mifc::ST_VORTDIV);
+  if (wind && !f1)
+    return 0;
+  const bool two_out = (op == mifc::ST_VORTDIV || op == mifc::ST_IGWIND);
+  const StencilCall sc = {op, nx, ny, nlev, f0, wind ? f1 : nullptr, xmapr, ymapr, fcoriolis, out0, two_out ? out1 : nullptr};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
 int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
                                 float* rvort, float* diverg, const int* fdefined_in, float undef, unsigned long long* n_undefined_dev)
 {

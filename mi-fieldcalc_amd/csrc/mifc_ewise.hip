@@ -10,6 +10,18 @@
 
 namespace mifc {
 
+// outputs are written once and never re-read by this library: nontemporal store
+__device__ __forceinline__ void store4_stream(float* p, float a, float b, float c, float d)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  v4f t;
+  t.x = a;
+  t.y = b;
+  t.z = c;
+  t.w = d;
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+
 namespace {
 
 // Point function of the single-field operators.  Returns true when the cell is
@@ -114,13 +126,29 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
   }
 }
 
+__host__ __device__ inline bool ewise_needs_ewt(const EwiseParams& P)
+{
+  return !(P.op == EW_VECTORABS || (P.op == EW_TEMP && P.compute >= 1 && P.compute <= 3));
+}
+__host__ __device__ inline bool ewise_needs_pow(const EwiseParams& P)
+{
+  return P.psrc != PS_SCALAR && (P.op == EW_TEMP || (P.op == EW_HUM && P.from_theta));
+}
+
 template <bool VEC4>
 __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
 {
   __shared__ float s_ewt[MIFC_N_EWT];
   __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
-  ewt_table_init(s_ewt);
-  const PowTables PT = pow_tables_init(s_pow);
+  // the lookup tables cost a few hundred cycles per workgroup: staged only
+  // for the operator variants that read them (wave-uniform conditions)
+  if (ewise_needs_ewt(P))
+    ewt_table_init(s_ewt);
+  PowTables PT;
+  PT.logt = s_pow;
+  PT.expt = s_pow + 2 * MIFC_POW_LOG_N;
+  if (ewise_needs_pow(P))
+    PT = pow_tables_init(s_pow);
 
   const bool use1 = P.in1 != nullptr;
   const bool use2 = P.in2 != nullptr;
@@ -154,7 +182,7 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
           bad += 1;
         }
       }
-      o4p[q] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      store4_stream(P.out + (size_t)q * 4, ov[0], ov[1], ov[2], ov[3]);
     }
     // tail cells (n not a multiple of 4) are handled by a second, scalar launch
   } else {
@@ -200,7 +228,11 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
   const int block = 256;
   if (vec_ok) {
     const int n4 = prm.n >> 2;
-    hipLaunchKernelGGL(ewise_kernel<true>, dim3(grid_for(n4, block, 256 * 16)), dim3(block), 0, stream, prm);
+    // Table-free variants: one float4 per lane, workgroups in address order (the
+    // streaming shape that measured fastest on MI355X).  Variants that stage
+    // lookup tables per workgroup amortise that over a grid-stride loop.
+    const bool tables = ewise_needs_ewt(prm) || ewise_needs_pow(prm);
+    hipLaunchKernelGGL(ewise_kernel<true>, dim3(grid_for(n4, block, tables ? 256 * 16 : 0x7fffffff)), dim3(block), 0, stream, prm);
     const int tail = prm.n - n4 * 4;
     if (tail > 0) {
       EwiseParams t = prm;
@@ -226,18 +258,6 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
 // three outputs (12 B)  => 28 B/cell + ps.  p = a + b*ps and powf(p*p0inv,
 // kappa) are evaluated once per cell and shared by rh (needs p) and theta
 // (needs pidcp).  grid.y = level; each lane owns 4 consecutive cells.
-// outputs are written once and never re-read by this library: nontemporal store
-__device__ __forceinline__ void store4_stream(float* p, float a, float b, float c, float d)
-{
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  v4f t;
-  t.x = a;
-  t.y = b;
-  t.z = c;
-  t.w = d;
-  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
-}
-
 template <bool CHECK>
 __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams P)
 {

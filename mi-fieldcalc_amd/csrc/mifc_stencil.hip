@@ -14,8 +14,8 @@
 // Two kernel families live here:
 //   stencil_cell_kernel   one lane per cell, any nx, every operator; used for
 //                         ragged widths, row slabs and the less common operators.
-//   (the fused, row-sliding vorticity+divergence kernel for the headline
-//    configuration is in mifc_vortdiv.hip)
+//   (the row-walking kernels that take over whenever nx % 4 == 0 are in
+//    mifc_vortdiv.hip -- wind operators -- and mifc_stencil_rows.hip)
 #include "mifc_device.h"
 #include "mifc_kernels.h"
 
@@ -190,14 +190,21 @@ hipError_t launch_cell(const StencilParams& prm, hipStream_t stream)
 } // namespace
 
 hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, bool* handled); // mifc_vortdiv.hip
+hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool* handled);  // mifc_stencil_rows.hip
 
 hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
 {
   if (prm.nlev <= 0)
     return hipSuccess;
-  if (prm.op == ST_VORTDIV || prm.op == ST_RELVORT || prm.op == ST_DIVERGENCE) {
+  if (prm.op == ST_VORTDIV || prm.op == ST_RELVORT || prm.op == ST_DIVERGENCE || prm.op == ST_ABSVORT) {
     bool handled = false;
     const hipError_t e = launch_vortdiv_rows(prm, stream, &handled);
+    if (handled)
+      return e;
+  }
+  if (prm.op >= ST_GRAD_X && prm.op <= ST_IGWIND) {
+    bool handled = false;
+    const hipError_t e = launch_scalar_rows(prm, stream, &handled);
     if (handled)
       return e;
   }

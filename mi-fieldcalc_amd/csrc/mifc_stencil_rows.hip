@@ -1,0 +1,420 @@
+// mifc_stencil_rows.hip -- row-walking kernel for the single-input stencil
+// operators: gradient compute 1..4 (FieldCalculations.cc:1985-2074),
+// plevelgwind_xcomp (:638), plevelgwind_ycomp (:674), plevelgvort (:708),
+// ilevelgwind (:1511).  Same machinery as the fused vorticity+divergence
+// kernel (mifc_vortdiv.hip), with one input field instead of two:
+//   * one wavefront = 64 lanes x V float4 (V separate 1-KiB segments) x R rows
+//     of one level; rows j-1, j, j+1 live in a static register ring, the next
+//     row is in flight (counted vmcnt waits, branch-free clamped loads);
+//   * x neighbours by DPP wave shifts, wave-column edges by one scalar per row;
+//   * the waves of a workgroup take consecutive levels of one tile; xmapr,
+//     ymapr, fcoriolis of the tile are staged once per workgroup in LDS;
+//   * address-order, XCD-aware block schedule; odd bands walk upwards so that
+//     shared halo rows meet in L2; nontemporal stores;
+//   * flat-loop semantics of the reference: wrapped neighbours at the edge
+//     columns take part in the undefined count, fillEdges is folded into the
+//     stores.
+// Algorithmic traffic: 4 B read + 4 B written per cell (8 B written for
+// ilevelgwind), map factors once per batch.
+#include "mifc_device.h"
+#include "mifc_kernels.h"
+
+#include <cstdlib>
+
+namespace mifc {
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct SRowsParams
+{
+  int nx, ny;
+  int R, nbands, nwc, nlev, wpb;
+  int uL, uB, uW, n_logical, per_xcd;
+  const float* f;
+  const float *xm, *ym, *fc; // any may be null when the operator does not use it
+  float *o0, *o1;
+  long in_stride, out_stride;
+  const unsigned char* all_defined;
+  float undef;
+  u64* n_undefined;
+};
+
+__device__ __forceinline__ float dpp_lower(float keep_if_none, float x)
+{
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_upper(float keep_if_none, float x)
+{
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_value(float x, int src_lane) // by value: see mifc_vortdiv.hip
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
+}
+__device__ __forceinline__ v4f ld4(const float* p)
+{
+  return *reinterpret_cast<const v4f*>(p);
+}
+__device__ __forceinline__ void st4_stream(float* p, const float (&z)[4])
+{
+  v4f t;
+  t.x = z[0];
+  t.y = z[1];
+  t.z = z[2];
+  t.w = z[3];
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
+}
+
+template <int V>
+struct SRow
+{
+  v4f f[V];
+  float e; // lane 63: value east of the wave-column; other lanes: value west of it
+};
+
+// One cell of operator OP.  w, c, e: row j; s, n: rows j-1, j+1.  Returns false
+// when the cell is undefined.  Formulas are those of stencil_raw() in
+// mifc_stencil.hip, i.e. of the reference lines cited there.
+template <int OP, bool CHECK>
+__device__ __forceinline__ bool scalar_cell(bool all, float undef, float w, float c, float e, float s, float n, float xm, float ym, float fc, float& o0,
+                                            float& o1)
+{
+  if (OP == ST_GRAD_X) { // :2015-2016
+    if (CHECK && !(all || (is_def(w, undef) && is_def(e, undef))))
+      return false;
+    o0 = (float)(0.5 * (double)xm * (double)(e - w));
+    return true;
+  }
+  if (OP == ST_GRAD_Y) { // :2027-2028
+    if (CHECK && !(all || (is_def(s, undef) && is_def(n, undef))))
+      return false;
+    o0 = (float)(0.5 * (double)ym * (double)(n - s));
+    return true;
+  }
+  if (OP == ST_GRAD_LAP || OP == ST_GVORT) {
+    if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(c, undef) && is_def(e, undef) && is_def(n, undef)))) // :2053, :729
+      return false;
+    const double dxm = xm, dym = ym;
+    if (OP == ST_GRAD_LAP) { // :2054-2056
+      const float d2x = (float)((double)w - 2.0 * (double)c + (double)e);
+      const float d2y = (float)((double)s - 2.0 * (double)c + (double)n);
+      o0 = (float)(4.0 * (0.25 * dxm * dxm * (double)d2x + 0.25 * dym * dym * (double)d2y));
+    } else { // :730-731
+      const float g4 = (float)((double)MIFC_K_G * 4.);
+      const double d2x = (double)w - 2. * (double)c + (double)e;
+      const double d2y = (double)s - 2. * (double)c + (double)n;
+      o0 = (float)((0.25 * dxm * dxm * d2x + 0.25 * dym * dym * d2y) * (double)g4 / (double)fc);
+    }
+    return true;
+  }
+  if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef)))) // :2039, :660, :693, :1534
+    return false;
+  if (OP == ST_GRAD_ABS) { // :2040-2042
+    const float dfdx = (float)(0.5 * (double)xm * (double)(e - w));
+    const float dfdy = (float)(0.5 * (double)ym * (double)(n - s));
+    o0 = absval(dfdx, dfdy);
+  } else if (OP == ST_GWIND_X) { // :661
+    o0 = (float)(-0.5 * (double)ym * (double)(n - s) * (double)MIFC_K_G / (double)fc);
+  } else if (OP == ST_GWIND_Y) { // :694
+    o0 = (float)(0.5 * (double)xm * (double)(e - w) * (double)MIFC_K_G / (double)fc);
+  } else { // ST_IGWIND :1535-1536
+    const double dfc = fc;
+    o0 = (float)(-0.5 * (double)ym * (double)(n - s) / dfc);
+    o1 = (float)(0.5 * (double)xm * (double)(e - w) / dfc);
+  }
+  return true;
+}
+
+template <int OP, bool CHECK, int V>
+__global__ __launch_bounds__(1024) void scalar_rows_kernel(const SRowsParams P)
+{
+  constexpr int W = 4; // ring: rows r-2 (being refilled), r-1, r, r+1
+  constexpr int WCOLS = 256 * V;
+  constexpr bool USE_XM = (OP != ST_GRAD_Y && OP != ST_GWIND_X);
+  constexpr bool USE_YM = (OP != ST_GRAD_X && OP != ST_GWIND_Y);
+  constexpr bool USE_FC = (OP == ST_GWIND_X || OP == ST_GWIND_Y || OP == ST_GVORT || OP == ST_IGWIND);
+  constexpr bool TWO_OUT = (OP == ST_IGWIND);
+
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int bid = blockIdx.x;
+  const int seq = (bid & 7) * P.per_xcd + (bid >> 3);
+  if (seq >= P.n_logical)
+    return;
+  // address order: level group slowest, then band, wave-column fastest
+  const int per_level = P.uB * P.uW;
+  const int lgroup = seq / per_level;
+  const int rem = seq - lgroup * per_level;
+  const int band = rem / P.uW;
+  const int wc = rem - band * P.uW;
+  const int lev0 = lgroup * P.wpb;
+
+  const int nx = P.nx;
+  int colq[V], colq_c[V];
+  bool actq[V];
+#pragma unroll
+  for (int q = 0; q < V; ++q) {
+    colq[q] = wc * WCOLS + q * 256 + lane * 4;
+    actq[q] = colq[q] < nx;
+    colq_c[q] = actq[q] ? colq[q] : nx - 4;
+  }
+  int east_col = wc * WCOLS + WCOLS;
+  if (east_col > nx)
+    east_col = nx;
+  const int edge_col = (lane == 63) ? east_col : (wc * WCOLS - 1);
+  const long idx_hi = (long)nx * P.ny - 1;
+
+  const int jb = 1 + band * P.R; // rows 1 .. ny-2 are computed
+  const int nr = (P.ny - 1 - jb < P.R) ? (P.ny - 1 - jb) : P.R;
+  const float undef = P.undef;
+  const bool up = (band & 1) != 0;
+
+  const bool valid = (lev0 + wave) < P.nlev;
+  const int lev = valid ? (lev0 + wave) : (P.nlev - 1);
+  const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
+  const float* __restrict__ f = P.f + (size_t)lev * P.in_stride;
+  float* o0p = P.o0 + (size_t)lev * P.out_stride;
+  float* o1p = TWO_OUT ? P.o1 + (size_t)lev * P.out_stride : nullptr;
+
+  auto load_row = [&](int t) -> SRow<V> {
+    const int tc = t > nr ? nr : t;
+    const int rowl = up ? (nr - 1 - tc) : tc;
+    const long base = (long)(jb + rowl) * nx;
+    SRow<V> r;
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      r.f[q] = ld4(f + base + colq_c[q]);
+    long e = base + edge_col;
+    e = e < 0 ? 0 : (e > idx_hi ? idx_hi : e);
+    r.e = f[e];
+    return r;
+  };
+  SRow<V> ring[W];
+#pragma unroll
+  for (int t = -1; t <= 1; ++t)
+    ring[(t + 2) % W] = load_row(t);
+
+  // map factors of the tile -> LDS, layout [array][row][segment][lane]
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  v4f* lds = reinterpret_cast<v4f*>(lds_raw);
+  const int tile4 = P.R * 64 * V;
+  for (int i = threadIdx.x; i < nr * 64 * V; i += blockDim.x) {
+    const int row = i / (64 * V);
+    int col = wc * WCOLS + (i - row * 64 * V) * 4;
+    col = col < nx ? col : nx - 4;
+    const long o = (long)(jb + row) * nx + col;
+    if (USE_XM)
+      lds[i] = ld4(P.xm + o);
+    if (USE_YM)
+      lds[tile4 + i] = ld4(P.ym + o);
+    if (USE_FC)
+      lds[2 * tile4 + i] = ld4(P.fc + o);
+  }
+  __syncthreads();
+  if (!valid)
+    return;
+
+  unsigned int bad = 0;
+  for (int rb = 0; rb < nr; rb += W) {
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+      const int r = rb + s;
+      if (r >= nr)
+        goto level_done;
+      ring[s % W] = load_row(r + 2); // replaces row r-2
+      const SRow<V>& rp = ring[(s + 1) % W];
+      const SRow<V>& rc = ring[(s + 2) % W];
+      const SRow<V>& rn = ring[(s + 3) % W];
+      const float east = lane_value(rc.e, 63);
+      const int rl = up ? (nr - 1 - r) : r;
+      const int j = jb + rl;
+
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        float fW = dpp_lower(rc.e, rc.f[q].w); // lane 0 keeps the west scalar
+        float fE = dpp_upper(rc.e, rc.f[q].x); // lane 63 keeps the east scalar
+        if (q > 0) {
+          const float t = lane_value(rc.f[q > 0 ? q - 1 : 0].w, 63);
+          fW = (lane == 0) ? t : fW;
+        }
+        if (q < V - 1) {
+          const float t = lane_value(rc.f[q < V - 1 ? q + 1 : q].x, 0);
+          fE = (lane == 63) ? t : fE;
+        }
+        if (colq[q] + 4 >= east_col)
+          fE = east;
+        const int li = (rl * V + q) * 64 + lane;
+        v4f xm4 = rc.f[q], ym4 = rc.f[q], fc4 = rc.f[q];
+        if (USE_XM)
+          xm4 = lds[li];
+        if (USE_YM)
+          ym4 = lds[tile4 + li];
+        if (USE_FC)
+          fc4 = lds[2 * tile4 + li];
+        const float fc6[6] = {fW, rc.f[q].x, rc.f[q].y, rc.f[q].z, rc.f[q].w, fE};
+        float z0[4], z1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float a = rp.f[q][k], b = rn.f[q][k]; // previous / next step of the walk
+          const float sv = up ? b : a;               // row j-1
+          const float nv = up ? a : b;               // row j+1
+          float r0 = undef, r1 = undef;
+          const bool ok = scalar_cell<OP, CHECK>(all, undef, fc6[k], fc6[k + 1], fc6[k + 2], sv, nv, xm4[k], ym4[k], fc4[k], r0, r1);
+          z0[k] = ok ? r0 : undef;
+          z1[k] = ok ? r1 : undef;
+          if (CHECK && !ok && actq[q])
+            bad += 1;
+        }
+        if (colq[q] == 0) { // fillEdges, column part
+          z0[0] = z0[1];
+          z1[0] = z1[1];
+        }
+        if (colq[q] + 4 == nx) {
+          z0[3] = z0[2];
+          z1[3] = z1[2];
+        }
+        if (actq[q]) {
+          const long o = (long)j * nx + colq[q];
+          st4_stream(o0p + o, z0);
+          if (j == 1) // fillEdges, row part
+            st4_stream(o0p + o - nx, z0);
+          if (j == P.ny - 2)
+            st4_stream(o0p + o + nx, z0);
+          if (TWO_OUT) {
+            st4_stream(o1p + o, z1);
+            if (j == 1)
+              st4_stream(o1p + o - nx, z1);
+            if (j == P.ny - 2)
+              st4_stream(o1p + o + nx, z1);
+          }
+        }
+      }
+    }
+  }
+level_done:
+  if (CHECK && P.n_undefined)
+    wave_count_add(P.n_undefined + lev, bad);
+}
+
+template <int OP>
+void launch_op(const SRowsParams& rp, bool check, int V, int grid, size_t lds, hipStream_t stream)
+{
+  const dim3 block(64 * rp.wpb);
+  if (check) {
+    if (V == 2)
+      hipLaunchKernelGGL((scalar_rows_kernel<OP, true, 2>), dim3(grid), block, lds, stream, rp);
+    else
+      hipLaunchKernelGGL((scalar_rows_kernel<OP, true, 1>), dim3(grid), block, lds, stream, rp);
+  } else {
+    if (V == 2)
+      hipLaunchKernelGGL((scalar_rows_kernel<OP, false, 2>), dim3(grid), block, lds, stream, rp);
+    else
+      hipLaunchKernelGGL((scalar_rows_kernel<OP, false, 1>), dim3(grid), block, lds, stream, rp);
+  }
+}
+
+inline bool a16(const void* p)
+{
+  return (reinterpret_cast<size_t>(p) & 15u) == 0;
+}
+
+} // namespace
+
+// Fast path for whole fields with nx % 4 == 0 and 16-byte aligned pointers;
+// otherwise *handled stays false and the one-lane-per-cell kernel runs.
+hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool* handled)
+{
+  *handled = false;
+  const int op = prm.op;
+  if (op < ST_GRAD_X || op > ST_IGWIND)
+    return hipSuccess;
+  const int nx = prm.nx, ny = prm.ny_global;
+  if (prm.j0 != 0 || prm.ny_local != ny || nx % 4 != 0 || nx < 8 || ny < 3)
+    return hipSuccess;
+  // gradient compute 1 counts over the flat range [1, nx*ny-1), i.e. also in
+  // rows 0 and ny-1 which this kernel does not walk: only its no-test variant is taken
+  if (op == ST_GRAD_X && !prm.every_level_all_defined)
+    return hipSuccess;
+  const bool use_xm = (op != ST_GRAD_Y && op != ST_GWIND_X);
+  const bool use_ym = (op != ST_GRAD_X && op != ST_GWIND_Y);
+  const bool use_fc = (op == ST_GWIND_X || op == ST_GWIND_Y || op == ST_GVORT || op == ST_IGWIND);
+  if (!a16(prm.f0) || !a16(prm.out0) || (use_xm && (!prm.xmapr || !a16(prm.xmapr))) || (use_ym && (!prm.ymapr || !a16(prm.ymapr))) ||
+      (use_fc && (!prm.fcoriolis || !a16(prm.fcoriolis))))
+    return hipSuccess;
+  if (op == ST_IGWIND && (!prm.out1 || !a16(prm.out1)))
+    return hipSuccess;
+  if (prm.in_level_stride % 4 != 0 || prm.out_level_stride % 4 != 0)
+    return hipSuccess;
+  if (std::getenv("MIFC_FORCE_CELL_KERNEL"))
+    return hipSuccess;
+
+  SRowsParams rp;
+  const int V = (nx > 256) ? 2 : 1;
+  rp.nx = nx;
+  rp.ny = ny;
+  rp.R = 8;
+  rp.nbands = (ny - 2 + rp.R - 1) / rp.R;
+  rp.nwc = (nx + 256 * V - 1) / (256 * V);
+  rp.nlev = prm.nlev;
+  int wpb = 8;
+  while (wpb > 1 && wpb / 2 >= prm.nlev)
+    wpb /= 2;
+  rp.wpb = wpb;
+  rp.uL = (prm.nlev + wpb - 1) / wpb;
+  rp.uB = rp.nbands;
+  rp.uW = rp.nwc;
+  const long n_logical = (long)rp.uL * rp.uB * rp.uW;
+  if (n_logical > 0x3fffffffL)
+    return hipSuccess;
+  rp.n_logical = (int)n_logical;
+  rp.per_xcd = (rp.n_logical + 7) / 8;
+  rp.f = prm.f0;
+  rp.xm = prm.xmapr;
+  rp.ym = prm.ymapr;
+  rp.fc = prm.fcoriolis;
+  rp.o0 = prm.out0;
+  rp.o1 = prm.out1;
+  rp.in_stride = prm.in_level_stride;
+  rp.out_stride = prm.out_level_stride;
+  rp.all_defined = prm.all_defined;
+  rp.undef = prm.undef;
+  rp.n_undefined = prm.n_undefined;
+  const int grid = rp.per_xcd * 8;
+  const size_t lds = (size_t)rp.R * 1024 * V * 3;
+  const bool check = !prm.every_level_all_defined;
+
+  *handled = true;
+  switch (op) {
+  case ST_GRAD_X:
+    launch_op<ST_GRAD_X>(rp, check, V, grid, lds, stream);
+    break;
+  case ST_GRAD_Y:
+    launch_op<ST_GRAD_Y>(rp, check, V, grid, lds, stream);
+    break;
+  case ST_GRAD_ABS:
+    launch_op<ST_GRAD_ABS>(rp, check, V, grid, lds, stream);
+    break;
+  case ST_GRAD_LAP:
+    launch_op<ST_GRAD_LAP>(rp, check, V, grid, lds, stream);
+    break;
+  case ST_GWIND_X:
+    launch_op<ST_GWIND_X>(rp, check, V, grid, lds, stream);
+    break;
+  case ST_GWIND_Y:
+    launch_op<ST_GWIND_Y>(rp, check, V, grid, lds, stream);
+    break;
+  case ST_GVORT:
+    launch_op<ST_GVORT>(rp, check, V, grid, lds, stream);
+    break;
+  default:
+    launch_op<ST_IGWIND>(rp, check, V, grid, lds, stream);
+    break;
+  }
+  return hipGetLastError();
+}
+
+} // namespace mifc

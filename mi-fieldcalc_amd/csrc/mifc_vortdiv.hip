@@ -71,6 +71,7 @@ struct RowsParams
   int zigzag;          // 1: odd bands walk upwards
   long idx_lo, idx_hi; // valid flat element range relative to owned row 0 (for clamped scalar loads)
   const float *u, *v, *xm, *ym;
+  const float* fc; // coriolis parameter, absvort only
   float *rv, *dv;
   long in_stride, out_stride;
   const unsigned char* all_defined;
@@ -146,7 +147,7 @@ __device__ __forceinline__ void decode_block(const RowsParams& P, int seq, int& 
   }
 }
 
-template <bool CHECK, bool WANT_V, bool WANT_D, int D, bool NT, int V>
+template <bool CHECK, bool WANT_V, bool WANT_D, bool ABSV, int D, bool NT, int V>
 __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
 {
   constexpr int W = D + 3;    // ring slots: rows r-2 (being refilled), r-1, r, r+1, r+2 .. r+D
@@ -241,6 +242,7 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   v4f* lds_xm = reinterpret_cast<v4f*>(lds_raw);
   v4f* lds_ym = lds_xm + P.R * 64 * V;
+  v4f* lds_fc = lds_ym + P.R * 64 * V; // only allocated / filled for absvort
   for (int i = threadIdx.x; i < nr * 64 * V; i += blockDim.x) {
     const int row = i / (64 * V);
     int col = wc * WCOLS + (i - row * 64 * V) * 4;
@@ -248,6 +250,8 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
     const long o = (long)(jb + row) * nx + col;
     lds_xm[i] = load4(P.xm + o);
     lds_ym[i] = load4(P.ym + o);
+    if (ABSV)
+      lds_fc[i] = load4(P.fc + o);
   }
   __syncthreads();
   if (!valid)
@@ -304,6 +308,9 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
           vE = east_v;
         }
         const v4f xm4 = lds_xm[(rl * V + q) * 64 + lane], ym4 = lds_ym[(rl * V + q) * 64 + lane];
+        v4f fc4 = xm4;
+        if (ABSV)
+          fc4 = lds_fc[(rl * V + q) * 64 + lane];
         const float uc[6] = {uW, rc.u[q].x, rc.u[q].y, rc.u[q].z, rc.u[q].w, uE};
         const float vc[6] = {vW, rc.v[q].x, rc.v[q].y, rc.v[q].z, rc.v[q].w, vE};
         float zv[4], zd[4];
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
           zv[k] = 0.f;
           zd[k] = 0.f;
           if (WANT_V)
-            zv[k] = ok ? f_relvort(xm4[k], ym4[k], ve - vw, dudy) : undef;
+            zv[k] = ok ? (ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, dudy, fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, dudy)) : undef;
           if (WANT_D)
             zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, dvdy) : undef;
           if (CHECK && !ok && actq[q])
@@ -372,7 +379,7 @@ level_done:
 struct Tuning
 {
   int R;     // rows per band
-  int D;     // rows kept in flight beyond the 3-row window (0..2)
+  int D;     // rows kept in flight beyond the 3-row window (0 or 1)
   int NT;    // nontemporal stores
   int V;     // float4 per lane and row (1 or 2): the wave covers 256*V columns
   int ORDER; // block order, see decode_block()
@@ -417,49 +424,42 @@ Tuning current_tuning(int nx)
     t.V = 1; // a second 256-column segment would be empty
   if (t.R < 1)
     t.R = 1;
-  const int rmax = 32 / t.V; // map-factor tile in LDS: 2*V KiB per row, 64 KiB at most
+  const int rmax = 20 / t.V; // map-factor tile in LDS: up to 3*V KiB per row (absvort), 64 KiB at most
   if (t.R > rmax)
     t.R = rmax;
   if (t.D < 0)
     t.D = 0;
-  if (t.D > 2)
-    t.D = 2;
-  if (t.V == 2 && t.D > 1)
-    t.D = 1; // the 5-row ring of 512-column rows does not fit 128 VGPRs without spilling
+  if (t.D > 1)
+    t.D = 1; // deeper rings were measured (no gain) and are not instantiated
   return t;
 }
 
-template <bool CHECK, bool WV, bool WD, int D, bool NT>
+template <bool CHECK, bool WV, bool WD, bool ABSV, int D, bool NT>
 void launch_v(const RowsParams& rp, const Tuning& t, int grid, hipStream_t stream)
 {
-  const size_t lds = (size_t)rp.R * 2048 * t.V;
+  const size_t lds = (size_t)rp.R * 1024 * t.V * (ABSV ? 3 : 2);
   if (t.V == 2)
-    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, D, NT, 2>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
+    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, ABSV, D, NT, 2>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
   else
-    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, D, NT, 1>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
+    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, ABSV, D, NT, 1>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
 }
 
-template <bool CHECK, bool WV, bool WD, int D>
-void launch_nt(const RowsParams& rp, const Tuning& t, int grid, hipStream_t stream)
-{
-  if (t.NT)
-    launch_v<CHECK, WV, WD, D, true>(rp, t, grid, stream);
-  else
-    launch_v<CHECK, WV, WD, D, false>(rp, t, grid, stream);
-}
-
-template <bool CHECK, bool WV, bool WD>
+template <bool CHECK, bool WV, bool WD, bool ABSV>
 void launch_d(const RowsParams& rp, const Tuning& t, int grid, hipStream_t stream)
 {
-  switch (t.D) {
+  const int sel = (t.D > 0 ? 1 : 0) | (t.NT ? 2 : 0);
+  switch (sel) {
   case 0:
-    launch_nt<CHECK, WV, WD, 0>(rp, t, grid, stream);
+    launch_v<CHECK, WV, WD, ABSV, 0, false>(rp, t, grid, stream);
     break;
   case 1:
-    launch_nt<CHECK, WV, WD, 1>(rp, t, grid, stream);
+    launch_v<CHECK, WV, WD, ABSV, 1, false>(rp, t, grid, stream);
+    break;
+  case 2:
+    launch_v<CHECK, WV, WD, ABSV, 0, true>(rp, t, grid, stream);
     break;
   default:
-    launch_nt<CHECK, WV, WD, 2>(rp, t, grid, stream);
+    launch_v<CHECK, WV, WD, ABSV, 1, true>(rp, t, grid, stream);
     break;
   }
 }
@@ -467,12 +467,14 @@ void launch_d(const RowsParams& rp, const Tuning& t, int grid, hipStream_t strea
 template <bool CHECK>
 void launch_outputs(const RowsParams& rp, const Tuning& t, int grid, hipStream_t stream)
 {
-  if (rp.rv && rp.dv)
-    launch_d<CHECK, true, true>(rp, t, grid, stream);
+  if (rp.fc)
+    launch_d<CHECK, true, false, true>(rp, t, grid, stream);
+  else if (rp.rv && rp.dv)
+    launch_d<CHECK, true, true, false>(rp, t, grid, stream);
   else if (rp.rv)
-    launch_d<CHECK, true, false>(rp, t, grid, stream);
+    launch_d<CHECK, true, false, false>(rp, t, grid, stream);
   else
-    launch_d<CHECK, false, true>(rp, t, grid, stream);
+    launch_d<CHECK, false, true, false>(rp, t, grid, stream);
 }
 
 inline bool aligned16(const void* p)
@@ -497,6 +499,10 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     rv = prm.out0;
   } else if (prm.op == ST_DIVERGENCE) {
     dv = prm.out0;
+  } else if (prm.op == ST_ABSVORT) {
+    rv = prm.out0;
+    if (!prm.fcoriolis || !aligned16(prm.fcoriolis))
+      return hipSuccess;
   } else {
     return hipSuccess;
   }
@@ -553,6 +559,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.v = prm.f1;
   rp.xm = prm.xmapr;
   rp.ym = prm.ymapr;
+  rp.fc = (prm.op == ST_ABSVORT) ? prm.fcoriolis : nullptr;
   rp.rv = rv;
   rp.dv = dv;
   rp.in_stride = prm.in_level_stride;

@@ -326,3 +326,44 @@ def test_headline_1440x720x137_properties(gpu_ctx, oracle):
     l = 5
     ok, e, f = oracle.call("relvort", nx, ny, du[l].cpu().numpy(), dv[l].cpu().numpy(), xm, ym, fdefined=SOME)
     assert cases.same_bits(rv3[l].cpu().numpy(), e, nan_payload=False) and f == fo3[l]
+
+
+# ------------------------------------------------------------------ generic batched stencils
+@pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 5), (260, 21, 4)])
+def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev):
+    """mifc_stencil_levels: each operator over a batch == the per-level reference call, flags included."""
+    import mi_fieldcalc_amd.synth as synth
+
+    xm, ym, fcor = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 606 + nx, nlev=nlev)
+    z = np.stack([synth.scalar_field(nx, ny, 700 + l) for l in range(nlev)])
+    flags = np.full(nlev, SOME, np.int32)
+    flags[0] = ALL
+    for l in range(1, nlev):
+        if l % 2:
+            u[l] = synth.sprinkle_undef(u[l], 10 + l, 0.03)
+            z[l] = synth.sprinkle_undef(z[l], 20 + l, 0.03)
+    table = [
+        ("relvort", "relvort", u, v, False, None, []), ("divergence", "divergence", u, v, False, None, []),
+        ("absvort", "absvort", u, v, True, None, []), ("vortdiv", None, u, v, False, None, []),
+        ("gradient1", "gradient", z, None, False, 1, []), ("gradient2", "gradient", z, None, False, 2, []),
+        ("gradient3", "gradient", z, None, False, 3, []), ("gradient4", "gradient", z, None, False, 4, []),
+        ("plevelgwind_xcomp", "plevelgwind_xcomp", z, None, True, None, []), ("plevelgwind_ycomp", "plevelgwind_ycomp", z, None, True, None, []),
+        ("plevelgvort", "plevelgvort", z, None, True, None, []), ("ilevelgwind", "ilevelgwind", z, None, True, None, []),
+    ]
+    for name, cpu_op, f0, f1, use_fc, compute, _ in table:
+        res = gpu_ctx.stencil_levels(name, f0, f1, xm, ym, fcor if use_fc else None, fdefined=flags)
+        assert res is not None, name
+        (o0, o1), fo = res
+        for l in range(nlev):
+            if name == "vortdiv":
+                ok, e0, f_e = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=int(flags[l]))
+                ok, e1, _ = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=int(flags[l]))
+            else:
+                args = [f0[l]] + ([f1[l]] if f1 is not None else []) + [xm, ym] + ([fcor] if use_fc else []) + ([compute] if compute else [])
+                ok, e, f_e = oracle.call(cpu_op, nx, ny, *args, fdefined=int(flags[l]))
+                e0, e1 = (e if isinstance(e, tuple) else (e, None))
+            assert cases.same_bits(o0[l], e0, nan_payload=False), (name, l)
+            if e1 is not None:
+                assert cases.same_bits(o1[l], e1, nan_payload=False), (name, l)
+            assert fo[l] == f_e, (name, l, fo[l], f_e)

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Per-operator table: every function on the hot path on a
+1440x720xNLEV device-resident batch -- GPU time of the synchronous batched call
+(kernel + flag read-back), algorithmic bytes, fraction of the HBM roofline --
+next to the reference CPU path (oracle/_ref when present, else the restatement)
+on one core for the same operator.
+
+    python tools/bench_ops.py [NLEV]      -> one JSON line per operator + a text table
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+
+import cpulib  # noqa: E402  (CPU baseline only)
+import mi_fieldcalc_amd as fc  # noqa: E402
+import mi_fieldcalc_amd.synth as synth  # noqa: E402
+
+NX, NY = 1440, 720
+NLEV = int(sys.argv[1]) if len(sys.argv) > 1 else 137
+PEAK = 8000.0
+DEV = torch.device("cuda", 0)
+ROUNDS = 5
+
+
+def gpu_time(fn):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(ROUNDS):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return float(np.median(ts))
+
+
+def cpu_rate(lib, op, args, nlev_cpu=4, min_s=1.5):
+    """Mcells/s of the CPU checker on one core; args are per-level numpy fields / scalars."""
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(nlev_cpu):
+            lib.call(op, NX, NY, *args, fdefined=fc.ALL_DEFINED)
+        n += nlev_cpu
+        if time.perf_counter() - t0 > min_s:
+            break
+    return NX * NY * n / (time.perf_counter() - t0) / 1e6
+
+
+def main():
+    which = "ref" if cpulib.available("ref") else "oracle"
+    cpu = cpulib.CpuLib(which)
+    ctx = fc.Context(0)
+    n = NX * NY
+    cells = n * NLEV
+    xm, ym, fcor = synth.grid_maps(NX, NY)
+    dxm, dym, dfc = (torch.from_numpy(a).to(DEV) for a in (xm, ym, fcor))
+    u, v = synth.device_wind(NX, NY, NLEV, 3, DEV)
+    z = (5500.0 + 10.0 * u).contiguous()
+    t, q, ps = synth.device_thermo(NX, NY, NLEV, 4, DEV)
+    # "tall field" view for the single-field elementwise operators: one field of NLEV*NY rows
+    tall = lambda x: x.reshape(NLEV * NY, NX)  # noqa: E731
+    ps_tall = ps.repeat(NLEV, 1).contiguous()
+    p_tall = (ps_tall * 0.7 + 10.0).contiguous()
+    rh = (q * 4000.0 + 5.0).contiguous()
+    out = torch.empty_like(u)
+    out2 = torch.empty_like(u)
+    flags = np.full(NLEV, fc.ALL_DEFINED, np.int32)
+    # host copies of ONE level for the CPU baseline
+    h = {k: x[0].cpu().numpy() for k, x in dict(u=u, v=v, z=z, t=t, q=q, rh=rh).items()}
+    h["ps"] = ps.cpu().numpy()
+    h["p"] = (h["ps"] * 0.7 + 10.0).astype(np.float32)
+
+    rows = []
+
+    def add(name, bytes_per_cell, once_bytes, gpu_fn, cpu_op, cpu_args):
+        ms = gpu_time(gpu_fn)
+        alg = cells * bytes_per_cell + once_bytes
+        cr = cpu_rate(cpu, cpu_op, cpu_args)
+        rec = {"op": name, "ms": round(ms, 4), "Mcells_per_s": round(cells / ms / 1e3, 1), "algorithmic_bytes": alg,
+               "GBps": round(alg / ms / 1e6, 1), "frac_of_8TBps": round(alg / ms / 1e6 / PEAK, 4),
+               "cpu_Mcells_per_s_1core": round(cr, 1), "cpu_kind": "reference" if which == "ref" else "port", "nlev": NLEV}
+        rows.append(rec)
+        print(json.dumps(rec), flush=True)
+
+    st = lambda op, f0, f1, fcc, two=False: (lambda: ctx.stencil_levels(op, f0, f1, dxm, dym, fcc, fdefined=flags, out0=out, out1=out2 if two else None))  # noqa: E731
+    add("relvort+divergence (fused)", 16, 8 * n, lambda: ctx.vortdiv_levels(u, v, dxm, dym, fdefined=flags, rvort=out, diverg=out2), "relvort", [h["u"], h["v"], xm, ym])
+    add("relvort", 12, 8 * n, st("relvort", u, v, None), "relvort", [h["u"], h["v"], xm, ym])
+    add("divergence", 12, 8 * n, st("divergence", u, v, None), "divergence", [h["u"], h["v"], xm, ym])
+    add("absvort", 12, 12 * n, st("absvort", u, v, dfc), "absvort", [h["u"], h["v"], xm, ym, fcor])
+    for c in (1, 2, 3, 4):
+        add("gradient compute=%d" % c, 8, 8 * n, st("gradient%d" % c, z, None, None), "gradient", [h["z"], xm, ym, c])
+    add("plevelgwind_xcomp", 8, 8 * n, st("plevelgwind_xcomp", z, None, dfc), "plevelgwind_xcomp", [h["z"], xm, ym, fcor])
+    add("plevelgwind_ycomp", 8, 8 * n, st("plevelgwind_ycomp", z, None, dfc), "plevelgwind_ycomp", [h["z"], xm, ym, fcor])
+    add("plevelgvort", 8, 12 * n, st("plevelgvort", z, None, dfc), "plevelgvort", [h["z"], xm, ym, fcor])
+    add("ilevelgwind", 12, 12 * n, st("ilevelgwind", z, None, dfc, True), "ilevelgwind", [h["z"], xm, ym, fcor])
+    o_t = tall(out)
+    add("vectorabs", 12, 0, lambda: ctx.vectorabs(tall(u), tall(v), fdefined=fc.ALL_DEFINED, out=o_t), "vectorabs", [h["u"], h["v"]])
+    add("pleveltemp c=3 (T->theta)", 8, 0, lambda: ctx.pleveltemp(tall(t), 850.0, "kelvin", 3, fdefined=fc.ALL_DEFINED, out=o_t), "pleveltemp", [h["t"], 850.0, "kelvin", 3])
+    add("hleveltemp c=3 (T->theta)", 12, 0, lambda: ctx.hleveltemp(tall(t), ps_tall, 12.5, 0.73, "kelvin", 3, fdefined=fc.ALL_DEFINED, out=o_t), "hleveltemp",
+        [h["t"], h["ps"], 12.5, 0.73, "kelvin", 3])
+    add("aleveltemp c=3 (T->theta)", 12, 0, lambda: ctx.aleveltemp(tall(t), p_tall, "kelvin", 3, fdefined=fc.ALL_DEFINED, out=o_t), "aleveltemp", [h["t"], h["p"], "kelvin", 3])
+    add("plevelhum c=1 (T,q->RH)", 12, 0, lambda: ctx.plevelhum(tall(t), tall(q), 850.0, "kelvin", 1, fdefined=fc.ALL_DEFINED, out=o_t), "plevelhum", [h["t"], h["q"], 850.0, "kelvin", 1])
+    add("hlevelhum c=1 (T,q->RH)", 16, 0, lambda: ctx.hlevelhum(tall(t), tall(q), ps_tall, 12.5, 0.73, "kelvin", 1, fdefined=fc.ALL_DEFINED, out=o_t), "hlevelhum",
+        [h["t"], h["q"], h["ps"], 12.5, 0.73, "kelvin", 1])
+    add("hlevelhum c=9 (T,q->Td K)", 16, 0, lambda: ctx.hlevelhum(tall(t), tall(q), ps_tall, 12.5, 0.73, "kelvin", 9, fdefined=fc.ALL_DEFINED, out=o_t), "hlevelhum",
+        [h["t"], h["q"], h["ps"], 12.5, 0.73, "kelvin", 9])
+    add("alevelhum c=2 (theta,q->RH)", 16, 0, lambda: ctx.alevelhum(tall(t), tall(q), p_tall, "kelvin", 2, fdefined=fc.ALL_DEFINED, out=o_t), "alevelhum", [h["t"], h["q"], h["p"], "kelvin", 2])
+    add("cvhum c=1 (T,RH->Td K)", 12, 0, lambda: ctx.cvhum(tall(t), tall(rh), "kelvin", 1, fdefined=fc.ALL_DEFINED, out=o_t), "cvhum", [h["t"], h["rh"], "kelvin", 1])
+    a, b = synth.hybrid_levels(NLEV)
+    add("fused ff+RH+theta (hybrid)", 28, 4 * n, lambda: ctx.hlevel_derived_levels(u, v, t, q, ps, a, b, fdef_wind=flags, fdef_thermo=flags,
+                                                                                    out={"ff": out, "rh": out2, "theta": o_t.reshape(NLEV, NY, NX)}),
+        "hlevelhum", [h["t"], h["q"], h["ps"], 12.5, 0.73, "kelvin", 1])
+    print()
+    print("%-30s %9s %12s %9s %7s %14s" % ("operator (1440x720x%d)" % NLEV, "GPU ms", "Mcells/s", "GB/s", "frac", "CPU Mcells/s"))
+    for r in rows:
+        print("%-30s %9.4f %12.0f %9.0f %7.3f %14.0f" % (r["op"], r["ms"], r["Mcells_per_s"], r["GBps"], r["frac_of_8TBps"], r["cpu_Mcells_per_s_1core"]))
+
+
+if __name__ == "__main__":
+    main()
