@@ -69,6 +69,7 @@ struct RowsParams
   int order;           // block sequence -> unit order, see decode_block()
   int xcd_remap;       // 1: sequence = (b % 8) * per_xcd + b / 8
   int zigzag;          // 1: odd bands walk upwards
+  int nt_interior;     // 1: rows no other band touches are loaded nontemporally
   long idx_lo, idx_hi; // valid flat element range relative to owned row 0 (for clamped scalar loads)
   const float *u, *v, *xm, *ym;
   const float* fc; // coriolis parameter, absvort only
@@ -210,11 +211,17 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
     const int tc = t > nr ? nr : t;
     const int rowl = up ? (nr - 1 - tc) : tc;
     const long base = (long)(jb + rowl) * nx;
+    const bool stream_row = P.nt_interior && tc >= 1 && tc <= nr - 2;
     RowRegs<V> r;
 #pragma unroll
     for (int q = 0; q < V; ++q) {
-      r.u[q] = load4(u + base + colq_c[q]);
-      r.v[q] = load4(v + base + colq_c[q]);
+      if (stream_row) { // interior row of the band: read once by this wave only
+        r.u[q] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(u + base + colq_c[q]));
+        r.v[q] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v + base + colq_c[q]));
+      } else { // first/last row of the band or a halo row: the neighbouring band reads it too
+        r.u[q] = load4(u + base + colq_c[q]);
+        r.v[q] = load4(v + base + colq_c[q]);
+      }
     }
 #ifdef MIFC_EXPERIMENT_NO_EDGE
     r.eu = 0.f; // timing experiment only: wrong at wave-column boundaries
@@ -386,6 +393,7 @@ struct Tuning
   int XCD;   // XCD-aware blockIdx remap
   int WPB;   // waves per workgroup: 4, 8 or 16 (levels side by side)
   int ZZ;    // odd bands walk upwards (halo rows meet in L2)
+  int NTI;   // nontemporal loads for the rows of a band that no other band reads
 };
 
 int tune_value(const char* s, const char* key, int dflt)
@@ -404,7 +412,7 @@ int tune_value(const char* s, const char* key, int dflt)
 
 Tuning current_tuning(int nx)
 {
-  Tuning t = {8, 1, 1, 2, 1, 1, 8, 1};
+  Tuning t = {8, 1, 1, 2, 1, 1, 4, 1, 0};
   // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,V=2,ORDER=1,XCD=1,WPB=8" -- used by the sweep tool and the tests
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     t.R = tune_value(s, "R", t.R);
@@ -415,6 +423,7 @@ Tuning current_tuning(int nx)
     t.XCD = tune_value(s, "XCD", t.XCD);
     t.WPB = tune_value(s, "WPB", t.WPB);
     t.ZZ = tune_value(s, "ZZ", t.ZZ);
+    t.NTI = tune_value(s, "NTI", t.NTI);
   }
   if (t.WPB != 1 && t.WPB != 2 && t.WPB != 4 && t.WPB != 8 && t.WPB != 16)
     t.WPB = 8;
@@ -555,6 +564,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.order = t.ORDER;
   rp.xcd_remap = t.XCD;
   rp.zigzag = t.ZZ;
+  rp.nt_interior = t.NTI;
   rp.u = prm.f0;
   rp.v = prm.f1;
   rp.xm = prm.xmapr;
