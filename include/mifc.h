@@ -118,6 +118,21 @@ int mifc_plevelgvort(mifc_ctx* ctx, int nx, int ny, const float* z, const float*
 int mifc_ilevelgwind(mifc_ctx* ctx, int nx, int ny, const float* mpot, const float* xmapr, const float* ymapr, const float* fcoriolis, float* ug,
                      float* vg, int* fdefined, float undef, int memkind);
 
+/* ---- next operators of the same family, one field per call -- */
+/* advection FieldCalculations.h:213 / .cc:1942; jacobian .h:235 / .cc:2424 */
+int mifc_advection(mifc_ctx* ctx, int nx, int ny, const float* f, const float* u, const float* v, const float* xmapr, const float* ymapr, float hours,
+                   float* advec, int* fdefined, float undef, int memkind);
+int mifc_jacobian(mifc_ctx* ctx, int nx, int ny, const float* field1, const float* field2, const float* xmapr, const float* ymapr, float* fjacobian,
+                  int* fdefined, float undef, int memkind);
+/* momentumXcoordinate .h:229 / .cc:2351; momentumYcoordinate .h:232 / .cc:2387 (pointwise) */
+int mifc_momentumXcoordinate(mifc_ctx* ctx, int nx, int ny, const float* v, const float* xmapr, const float* fcoriolis, float fcoriolisMin, float* mxy,
+                             int* fdefined, float undef, int memkind);
+int mifc_momentumYcoordinate(mifc_ctx* ctx, int nx, int ny, const float* u, const float* ymapr, const float* fcoriolis, float fcoriolisMin, float* nxy,
+                             int* fdefined, float undef, int memkind);
+/* thermalFrontParameter .h:225 / .cc:2266 (two passes: |grad T|, then the front parameter) */
+int mifc_thermalFrontParameter(mifc_ctx* ctx, int nx, int ny, const float* tx, const float* xmapr, const float* ymapr, float* tfp, int* fdefined,
+                               float undef, int memkind);
+
 /* ---- batched over vertical levels / ensemble members (new surface) ------ */
 /* The reference is called once per 2-D field; a caller that wants vorticity
  * AND divergence on nlev levels makes 2*nlev calls.  These

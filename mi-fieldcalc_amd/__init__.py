@@ -225,6 +225,22 @@ class Context:
     def ilevelgwind(self, mpot, xmapr, ymapr, fcoriolis, fdefined=SOME_DEFINED, undef=UNDEF, out=(None, None)):
         return self._single("mifc_ilevelgwind", [mpot, xmapr, ymapr, fcoriolis], [], list(out), fdefined, undef, n_out=2)
 
+    # ------------------------------------------ next operators
+    def advection(self, f, u, v, xmapr, ymapr, hours, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_advection", [f, u, v, xmapr, ymapr], [float(hours)], [out], fdefined, undef)
+
+    def jacobian(self, field1, field2, xmapr, ymapr, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_jacobian", [field1, field2, xmapr, ymapr], [], [out], fdefined, undef)
+
+    def momentumXcoordinate(self, v, xmapr, fcoriolis, fcoriolisMin, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_momentumXcoordinate", [v, xmapr, fcoriolis], [float(fcoriolisMin)], [out], fdefined, undef)
+
+    def momentumYcoordinate(self, u, ymapr, fcoriolis, fcoriolisMin, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_momentumYcoordinate", [u, ymapr, fcoriolis], [float(fcoriolisMin)], [out], fdefined, undef)
+
+    def thermalFrontParameter(self, tx, xmapr, ymapr, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_thermalFrontParameter", [tx, xmapr, ymapr], [], [out], fdefined, undef)
+
     # ------------------------------------------------------------------ batched
     def vortdiv_levels(self, u, v, xmapr, ymapr, fdefined=None, undef=UNDEF, rvort=None, diverg=None, want=("rvort", "diverg")):
         """Fused relvort + divergence over u, v of shape (nlev, ny, nx).

@@ -59,6 +59,12 @@ SIGNATURES = {
     "mifc_plevelgwind_ycomp": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_plevelgvort": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_ilevelgwind": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    # SURVEY.md 8f-1
+    "mifc_advection": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "f", "p", "pi", "f", "i"]),
+    "mifc_jacobian": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_momentumXcoordinate": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "p", "pi", "f", "i"]),
+    "mifc_momentumYcoordinate": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "p", "pi", "f", "i"]),
+    "mifc_thermalFrontParameter": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "pi", "f", "i"]),
     # batched
     "mifc_vortdiv_levels": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_stencil_levels": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),

@@ -257,6 +257,8 @@ struct StencilCall
   int nx, ny, nlev;
   const float *f0, *f1, *xm, *ym, *fc;
   float *o0, *o1;
+  const float* f2; // third input field (advection)
+  float scale;     // advection
 };
 
 // count range of the raw loop -> what the flag is classified against
@@ -290,6 +292,8 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
   P.fcoriolis = stage_in(c, 4, sc.fc, n, memkind, &ok);
   P.out0 = stage_out(c, 5, sc.o0, nb, memkind, &ok);
   P.out1 = stage_out(c, 6, sc.o1, nb, memkind, &ok);
+  P.f2 = stage_in(c, 7, sc.f2, nb, memkind, &ok);
+  P.scale = sc.scale;
   if (!ok || !ensure_levels(c, (size_t)sc.nlev))
     return 0;
   if (sc.op == mifc::ST_VORTDIV && !P.out0 && P.out1) {
@@ -312,6 +316,12 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
     pinned_flags(c)[l] = a ? 1 : 0;
     every_all = every_all && a;
   }
+  // the second pass of thermalFrontParameter rejects cells (|grad T| == 0) even
+  // when its input flag is ALL_DEFINED: it always runs the counting variant
+  const bool flags_say_all = every_all;
+  if (sc.op == mifc::ST_TFP)
+    every_all = false;
+  (void)flags_say_all;
   P.every_level_all_defined = every_all ? 1 : 0;
   P.all_defined = c->d_flags;
   if (!every_all) {
@@ -810,6 +820,89 @@ int mifc_ilevelgwind(mifc_ctx* c, int nx, int ny, const float* mpot, const float
   c->err.clear();
   const StencilCall sc = {mifc::ST_IGWIND, nx, ny, 1, mpot, nullptr, xmapr, ymapr, fcoriolis, ug, vg};
   return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+// ------------------------------------------------ SURVEY.md 8f-1 operators
+
+int mifc_advection(mifc_ctx* c, int nx, int ny, const float* f, const float* u, const float* v, const float* xmapr, const float* ymapr, float hours,
+                   float* advec, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  StencilCall sc = {mifc::ST_ADVECTION, nx, ny, 1, f, u, xmapr, ymapr, nullptr, advec, nullptr};
+  sc.f2 = v;
+  sc.scale = (float)(-3600. * (double)hours); // FieldCalculations.cc:1963
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+int mifc_jacobian(mifc_ctx* c, int nx, int ny, const float* field1, const float* field2, const float* xmapr, const float* ymapr, float* fjacobian,
+                  int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  const StencilCall sc = {mifc::ST_JACOBIAN, nx, ny, 1, field1, field2, xmapr, ymapr, nullptr, fjacobian, nullptr};
+  return run_stencil(c, sc, fdefined, undef, memkind);
+}
+
+static int momentum_coordinate(mifc_ctx* c, int op, int nx, int ny, const float* wind, const float* mapr, const float* fcoriolis, float fcoriolisMin,
+                               float* out, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (nx < 3 || ny < 3) // :2363, :2397
+    return 0;
+  mifc::EwiseParams P = ewise_base(op, nx, ny, fdefined, undef);
+  P.nx = nx;
+  P.fcormin = fabsf(fcoriolisMin); // :2366
+  return run_ewise(c, P, wind, mapr, fcoriolis, out, fdefined, memkind, false);
+}
+
+int mifc_momentumXcoordinate(mifc_ctx* c, int nx, int ny, const float* v, const float* xmapr, const float* fcoriolis, float fcoriolisMin, float* mxy,
+                             int* fdefined, float undef, int memkind)
+{
+  return momentum_coordinate(c, mifc::EW_MOMENTUM_X, nx, ny, v, xmapr, fcoriolis, fcoriolisMin, mxy, fdefined, undef, memkind);
+}
+
+int mifc_momentumYcoordinate(mifc_ctx* c, int nx, int ny, const float* u, const float* ymapr, const float* fcoriolis, float fcoriolisMin, float* nxy,
+                             int* fdefined, float undef, int memkind)
+{
+  return momentum_coordinate(c, mifc::EW_MOMENTUM_Y, nx, ny, u, ymapr, fcoriolis, fcoriolisMin, nxy, fdefined, undef, memkind);
+}
+
+// thermalFrontParameter, FieldCalculations.cc:2266-2309: two passes with an
+// intermediate |grad T| field that lives in the context's scratch.  The second
+// pass takes its "all defined" from the flag the first pass returned (:2286).
+int mifc_thermalFrontParameter(mifc_ctx* c, int nx, int ny, const float* tx, const float* xmapr, const float* ymapr, float* tfp, int* fdefined,
+                               float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (nx < 3 || ny < 3) // gradient() :2004
+    return 0;
+  const size_t n = (size_t)nx * ny;
+  bool ok = true;
+  // bring the inputs to the device once; both passes then run on device pointers
+  const float* d_tx = stage_in(c, 0, tx, n, memkind, &ok);
+  const float* d_xm = stage_in(c, 2, xmapr, n, memkind, &ok);
+  const float* d_ym = stage_in(c, 3, ymapr, n, memkind, &ok);
+  float* d_out = stage_out(c, 5, tfp, n, memkind, &ok);
+  if (!ok || !ensure_slot(c, 8, n * sizeof(float)))
+    return 0;
+  float* d_absdelt = static_cast<float*>(c->slot[8]);
+  const StencilCall pass1 = {mifc::ST_GRAD_ABS, nx, ny, 1, d_tx, nullptr, d_xm, d_ym, nullptr, d_absdelt, nullptr};
+  if (!run_stencil(c, pass1, fdefined, undef, MIFC_MEM_DEVICE))
+    return 0;
+  const StencilCall pass2 = {mifc::ST_TFP, nx, ny, 1, d_tx, d_absdelt, d_xm, d_ym, nullptr, d_out, nullptr};
+  if (!run_stencil(c, pass2, fdefined, undef, MIFC_MEM_DEVICE))
+    return 0;
+  if (!fetch_out(c, 5, tfp, n, memkind))
+    return 0;
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  return 1;
 }
 
 // ----------------------------------------------------------------- batched

@@ -28,7 +28,8 @@ namespace {
 // defined (r holds the value); false => cell := undef and is counted.
 // `keep` is set for the one case where the reference leaves a defined cell
 // unwritten (hleveltemp with compute outside 1..5, FieldCalculations.cc:1080-1090).
-__device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* tab, const PowTables& PT, float a, float b, float c, float& r, bool& keep)
+__device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* tab, const PowTables& PT, int cell, float a, float b, float c, float& r,
+                                            bool& keep)
 {
   const bool all = P.all_defined != 0;
   const float undef = P.undef;
@@ -113,7 +114,7 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
     r = e.inverse(tab, rh * et) + P.tdconv;
     return true;
   }
-  default: { // EW_CVHUM_RH :1792-1808
+  case EW_CVHUM_RH: { // :1792-1808
     if (!(all || (is_def(a, undef) && is_def(b, undef))))
       return false;
     const Ewt e(a - P.tconv), e2(b - P.tconv);
@@ -123,12 +124,26 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
     r = rh * P.unit_scale;
     return true;
   }
+  default: { // EW_MOMENTUM_X / _Y :2371-2379, :2407-2415 (a = wind component, b = map ratio, c = coriolis)
+    if (!(all || is_def(a, undef)))
+      return false;
+    float fcor = c;
+    if (fcor >= 0.f && fcor < P.fcormin)
+      fcor = P.fcormin;
+    else if (fcor <= 0.f && fcor > -P.fcormin)
+      fcor = -P.fcormin;
+    if (P.op == EW_MOMENTUM_X)
+      r = (float)(cell % P.nx) + a * b / fcor;
+    else
+      r = (float)(cell / P.nx) - a * b / fcor;
+    return true;
+  }
   }
 }
 
 __host__ __device__ inline bool ewise_needs_ewt(const EwiseParams& P)
 {
-  return !(P.op == EW_VECTORABS || (P.op == EW_TEMP && P.compute >= 1 && P.compute <= 3));
+  return !(P.op == EW_VECTORABS || P.op == EW_MOMENTUM_X || P.op == EW_MOMENTUM_Y || (P.op == EW_TEMP && P.compute >= 1 && P.compute <= 3));
 }
 __host__ __device__ inline bool ewise_needs_pow(const EwiseParams& P)
 {
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
       for (int k = 0; k < 4; ++k) {
         float r = 0.f;
         bool keep;
-        if (ewise_point(P, s_ewt, PT, av[k], bv[k], cv[k], r, keep)) {
+        if (ewise_point(P, s_ewt, PT, q * 4 + k, av[k], bv[k], cv[k], r, keep)) {
           if (!keep)
             ov[k] = r;
         } else {
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
       const float c = use2 ? P.in2[i] : 0.f;
       float r = 0.f;
       bool keep;
-      if (ewise_point(P, s_ewt, PT, a, b, c, r, keep)) {
+      if (ewise_point(P, s_ewt, PT, i + P.cell0, a, b, c, r, keep)) {
         if (!keep)
           P.out[i] = r;
       } else {
@@ -241,6 +256,7 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
       t.in1 = prm.in1 ? prm.in1 + n4 * 4 : nullptr;
       t.in2 = prm.in2 ? prm.in2 + n4 * 4 : nullptr;
       t.out = prm.out + n4 * 4;
+      t.cell0 = n4 * 4;
       hipLaunchKernelGGL(ewise_kernel<false>, dim3(1), dim3(64), 0, stream, t);
     }
   } else {

@@ -15,7 +15,9 @@ enum EwiseOp {
   EW_TEMP = 1,      // pleveltemp :328, hleveltemp :1046, aleveltemp :1310
   EW_HUM = 2,       // plevelhum :400, hlevelhum :1145, alevelhum :1394
   EW_CVHUM_TD = 3,  // cvhum compute 1..3 :1759-1785
-  EW_CVHUM_RH = 4   // cvhum compute 4,5 :1787-1811
+  EW_CVHUM_RH = 4,  // cvhum compute 4,5 :1787-1811
+  EW_MOMENTUM_X = 5, // momentumXcoordinate :2351: in0 = v, in1 = xmapr, in2 = fcoriolis
+  EW_MOMENTUM_Y = 6  // momentumYcoordinate :2387: in0 = u, in1 = ymapr, in2 = fcoriolis
 };
 enum PressureSource { PS_SCALAR = 0, PS_HYBRID = 1, PS_FIELD = 2 };
 enum HumKind { HUM_Q_RH = 0, HUM_RH_Q = 1, HUM_Q_TD = 2, HUM_RH_TD = 3 };
@@ -40,6 +42,9 @@ struct EwiseParams
   float tdconv;   // :437, :1181, :1423, :1754
   float alevel, blevel;
   float unit_scale; // cvhum :1746-1750
+  int nx;           // momentum coordinates: row length (cell index -> column / row)
+  int cell0;        // index of in0[0] inside the field (non-zero only for the scalar tail launch)
+  float fcormin;    // momentum coordinates: |fcoriolisMin| (:2366)
   float undef;
   const float* in0; // u | t
   const float* in1; // v | hum
@@ -84,7 +89,11 @@ enum StencilOp {
   ST_GWIND_X = 8,    // plevelgwind_xcomp :638
   ST_GWIND_Y = 9,    // plevelgwind_ycomp :674
   ST_GVORT = 10,     // plevelgvort :708
-  ST_IGWIND = 11     // ilevelgwind :1511, two outputs
+  ST_IGWIND = 11,    // ilevelgwind :1511, two outputs
+  // SURVEY.md 8f-1 (one-lane-per-cell kernel only, so far)
+  ST_ADVECTION = 12, // advection :1942: f0 = f, f1 = u, f2 = v, scale = -3600*hours
+  ST_JACOBIAN = 13,  // jacobian :2424: f0 = field1, f1 = field2
+  ST_TFP = 14        // second pass of thermalFrontParameter :2289-2302: f0 = tx, f1 = |grad tx|
 };
 
 struct StencilParams
@@ -98,6 +107,8 @@ struct StencilParams
   // f0/f1 point at OWNED row 0; for a slab the halo rows sit directly before and after
   const float* f0; // u | z | field | mpot
   const float* f1; // v (uv family only)
+  const float* f2; // third input (advection: v)
+  float scale;     // advection: -3600 * hours, rounded to float like the reference (:1963)
   const float* xmapr;
   const float* ymapr;
   const float* fcoriolis;

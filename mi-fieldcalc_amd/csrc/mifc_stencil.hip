@@ -58,6 +58,48 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
     }
     return true;
   }
+  if (OP == ST_ADVECTION) { // :1971-1972
+    const float* f = f0;
+    const float uc = f1[p], vc = P.f2[p + (size_t)blockIdx.y * P.in_level_stride]; // blockIdx.y = level of this launch
+    const float s = f[p - nx], w = f[p - 1], e = f[p + 1], n = f[p + nx];
+    if (CHECK && !(all || (is_def(uc, undef) && is_def(vc, undef) && is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef))))
+      return false;
+    o.o0 = (float)(((double)uc * 0.5 * (double)P.xmapr[p] * (double)(e - w) + (double)vc * 0.5 * (double)P.ymapr[p] * (double)(n - s)) * (double)P.scale);
+    return true;
+  }
+  if (OP == ST_JACOBIAN) { // :2443-2451: four float-rounded partials, float combination
+    const float* a = f0;
+    const float* b = f1;
+    const float as = a[p - nx], aw = a[p - 1], ae = a[p + 1], an = a[p + nx];
+    const float bs = b[p - nx], bw = b[p - 1], be = b[p + 1], bn = b[p + nx];
+    if (CHECK && !(all || (is_def(as, undef) && is_def(aw, undef) && is_def(ae, undef) && is_def(an, undef) && is_def(bs, undef) && is_def(bw, undef) &&
+                           is_def(be, undef) && is_def(bn, undef))))
+      return false;
+    const double hx = 0.5 * (double)P.xmapr[p], hy = 0.5 * (double)P.ymapr[p];
+    const float df1dx = (float)(hx * (double)(ae - aw));
+    const float df1dy = (float)(hy * (double)(an - as));
+    const float df2dx = (float)(hx * (double)(be - bw));
+    const float df2dy = (float)(hy * (double)(bn - bs));
+    o.o0 = df1dx * df2dy - df1dy * df2dx;
+    return true;
+  }
+  if (OP == ST_TFP) { // :2290-2298; the "!= 0" test runs even when the flag says ALL_DEFINED
+    const float* t = f0;
+    const float* g = f1; // |grad t| with its edges filled
+    const float ts = t[p - nx], tw = t[p - 1], te = t[p + 1], tn = t[p + nx];
+    const float gs = g[p - nx], gw = g[p - 1], gc = g[p], ge = g[p + 1], gn = g[p + nx];
+    const bool def = all || (is_def(ts, undef) && is_def(tw, undef) && is_def(te, undef) && is_def(tn, undef) && is_def(gs, undef) && is_def(gw, undef) &&
+                             is_def(gc, undef) && is_def(ge, undef) && is_def(gn, undef));
+    if (!(def && gc != 0))
+      return false;
+    const double hx = 0.5 * (double)P.xmapr[p], hy = 0.5 * (double)P.ymapr[p];
+    const float dabsdeltdx = (float)(hx * (double)(ge - gw));
+    const float dabsdeltdy = (float)(hy * (double)(gn - gs));
+    const float dtdxa = (float)(hx * (double)(te - tw) / (double)gc);
+    const float dtdya = (float)(hy * (double)(tn - ts) / (double)gc);
+    o.o0 = -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya);
+    return true;
+  }
   const float* f = f0;
   if (OP == ST_GRAD_X) { // :2015-2016
     const float w = f[p - 1], e = f[p + 1];
@@ -142,7 +184,7 @@ __global__ __launch_bounds__(256) void stencil_cell_kernel(const StencilParams P
     if ((OP == ST_VORTDIV || OP == ST_IGWIND) && out1)
       out1[i] = o.o1;
 
-    if (CHECK && !all) {
+    if (CHECK && (!all || OP == ST_TFP)) { // TFP rejects |grad T| == 0 cells whatever the input flag says
       // Count over the raw loop range, with the wrapped neighbours the flat
       // loop sees at the edge columns (Appendix A #6).
       const long gi = (long)j * nx + c;
@@ -175,6 +217,7 @@ hipError_t launch_cell(const StencilParams& prm, hipStream_t stream)
     const int nl = (prm.nlev - l0 > 65535) ? 65535 : (prm.nlev - l0);
     p.f0 = prm.f0 + (size_t)l0 * prm.in_level_stride;
     p.f1 = prm.f1 ? prm.f1 + (size_t)l0 * prm.in_level_stride : nullptr;
+    p.f2 = prm.f2 ? prm.f2 + (size_t)l0 * prm.in_level_stride : nullptr;
     p.out0 = prm.out0 + (size_t)l0 * prm.out_level_stride;
     p.out1 = prm.out1 ? prm.out1 + (size_t)l0 * prm.out_level_stride : nullptr;
     p.all_defined = prm.all_defined ? prm.all_defined + l0 : nullptr;
@@ -233,6 +276,12 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
     return launch_cell<ST_GVORT>(prm, stream);
   case ST_IGWIND:
     return launch_cell<ST_IGWIND>(prm, stream);
+  case ST_ADVECTION:
+    return launch_cell<ST_ADVECTION>(prm, stream);
+  case ST_JACOBIAN:
+    return launch_cell<ST_JACOBIAN>(prm, stream);
+  case ST_TFP:
+    return launch_cell<ST_TFP>(prm, stream);
   default:
     return hipErrorInvalidValue;
   }

@@ -100,6 +100,18 @@ bool divergence(int nx, int ny, const float* u, const float* v, const float* xma
 bool gradient(int nx, int ny, const float* field, const float* xmapr, const float* ymapr, int compute,
               float* fgrad, ValuesDefined& fDefined, float undef);
 
+// ---- same family, next in line (advection .. thermal front parameter) ----------
+bool advection(int nx, int ny, const float* f, const float* u, const float* v, const float* xmapr, const float* ymapr, float hours,
+               float* advec, ValuesDefined& fDefined, float undef);
+bool jacobian(int nx, int ny, const float* field1, const float* field2, const float* xmapr, const float* ymapr,
+              float* fjacobian, ValuesDefined& fDefined, float undef);
+bool momentumXcoordinate(int nx, int ny, const float* v, const float* xmapr, const float* fcoriolis, float fcoriolisMin,
+                         float* mxy, ValuesDefined& fDefined, float undef);
+bool momentumYcoordinate(int nx, int ny, const float* u, const float* ymapr, const float* fcoriolis, float fcoriolisMin,
+                         float* nxy, ValuesDefined& fDefined, float undef);
+bool thermalFrontParameter(int nx, int ny, const float* t, const float* xmapr, const float* ymapr,
+                           float* tfp, ValuesDefined& fDefined, float undef);
+
 // ---- extensions of this implementation (not in the reference) -----------------
 // Fused relvort + divergence for nlev levels stored [nlev][ny][nx]; xmapr/ymapr
 // are shared.  fDefined[l] in/out per level.  Either output may be null.

@@ -173,6 +173,40 @@ bool gradient(int nx, int ny, const float* field, const float* xmapr, const floa
   return mifc_gradient(context(), nx, ny, field, xmapr, ymapr, compute, fgrad, f.ptr(), undef, MIFC_MEM_HOST) != 0;
 }
 
+bool advection(int nx, int ny, const float* f_, const float* u, const float* v, const float* xmapr, const float* ymapr, float hours, float* advec,
+               ValuesDefined& fDefined, float undef)
+{
+  FlagIO f(fDefined);
+  return mifc_advection(context(), nx, ny, f_, u, v, xmapr, ymapr, hours, advec, f.ptr(), undef, MIFC_MEM_HOST) != 0;
+}
+
+bool jacobian(int nx, int ny, const float* field1, const float* field2, const float* xmapr, const float* ymapr, float* fjacobian,
+              ValuesDefined& fDefined, float undef)
+{
+  FlagIO f(fDefined);
+  return mifc_jacobian(context(), nx, ny, field1, field2, xmapr, ymapr, fjacobian, f.ptr(), undef, MIFC_MEM_HOST) != 0;
+}
+
+bool momentumXcoordinate(int nx, int ny, const float* v, const float* xmapr, const float* fcoriolis, float fcoriolisMin, float* mxy,
+                         ValuesDefined& fDefined, float undef)
+{
+  FlagIO f(fDefined);
+  return mifc_momentumXcoordinate(context(), nx, ny, v, xmapr, fcoriolis, fcoriolisMin, mxy, f.ptr(), undef, MIFC_MEM_HOST) != 0;
+}
+
+bool momentumYcoordinate(int nx, int ny, const float* u, const float* ymapr, const float* fcoriolis, float fcoriolisMin, float* nxy,
+                         ValuesDefined& fDefined, float undef)
+{
+  FlagIO f(fDefined);
+  return mifc_momentumYcoordinate(context(), nx, ny, u, ymapr, fcoriolis, fcoriolisMin, nxy, f.ptr(), undef, MIFC_MEM_HOST) != 0;
+}
+
+bool thermalFrontParameter(int nx, int ny, const float* t, const float* xmapr, const float* ymapr, float* tfp, ValuesDefined& fDefined, float undef)
+{
+  FlagIO f(fDefined);
+  return mifc_thermalFrontParameter(context(), nx, ny, t, xmapr, ymapr, tfp, f.ptr(), undef, MIFC_MEM_HOST) != 0;
+}
+
 bool vortdiv_levels(int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr, float* rvort, float* diverg,
                     std::vector<ValuesDefined>& fDefined, float undef)
 {

@@ -822,4 +822,152 @@ int mifcorc_cvhum(int nx, int ny, const float* t, const float* huminp, const cha
   return 1;
 }
 
+// ---------------------------------------------------------------- SURVEY.md 8f-1
+
+// FieldCalculations.cc:1942-1983
+int mifcorc_advection(int nx, int ny, const float* f, const float* u, const float* v, const float* xmapr, const float* ymapr, float hours, float* advec,
+                      int* fdefined, float undef)
+{
+  if (nx < 3 || ny < 3)
+    return 0;
+  const float scale = (float)(-3600. * (double)hours);
+  const int n = nx * ny;
+  const bool all = (*fdefined == ALL_DEFINED);
+  const size_t bad = flat_loop(nx, n - nx, [&](int i) {
+    if (!(all || (defined1(u[i], undef) && defined1(v[i], undef) && defined1(f[i - nx], undef) && defined1(f[i - 1], undef) &&
+                  defined1(f[i + 1], undef) && defined1(f[i + nx], undef)))) {
+      advec[i] = undef;
+      return false;
+    }
+    const float dx = f[i + 1] - f[i - 1];
+    const float dy = f[i + nx] - f[i - nx];
+    advec[i] = (float)(((double)u[i] * 0.5 * (double)xmapr[i] * (double)dx + (double)v[i] * 0.5 * (double)ymapr[i] * (double)dy) * (double)scale);
+    return true;
+  });
+  *fdefined = classify(bad, n - 2 * nx);
+  fill_edges(nx, ny, advec);
+  return 1;
+}
+
+// FieldCalculations.cc:2424-2460: the four partials are rounded to float, the
+// combination is float arithmetic
+int mifcorc_jacobian(int nx, int ny, const float* f1, const float* f2, const float* xmapr, const float* ymapr, float* out, int* fdefined, float undef)
+{
+  if (nx < 3 || ny < 3)
+    return 0;
+  const int n = nx * ny;
+  const bool all = (*fdefined == ALL_DEFINED);
+  const size_t bad = flat_loop(nx, n - nx, [&](int i) {
+    if (!(all || (defined1(f1[i - nx], undef) && defined1(f1[i - 1], undef) && defined1(f1[i + 1], undef) && defined1(f1[i + nx], undef) &&
+                  defined1(f2[i - nx], undef) && defined1(f2[i - 1], undef) && defined1(f2[i + 1], undef) && defined1(f2[i + nx], undef)))) {
+      out[i] = undef;
+      return false;
+    }
+    const float a = f1[i + 1] - f1[i - 1], b = f1[i + nx] - f1[i - nx], c = f2[i + 1] - f2[i - 1], d = f2[i + nx] - f2[i - nx];
+    const float df1dx = (float)(0.5 * (double)xmapr[i] * (double)a);
+    const float df1dy = (float)(0.5 * (double)ymapr[i] * (double)b);
+    const float df2dx = (float)(0.5 * (double)xmapr[i] * (double)c);
+    const float df2dy = (float)(0.5 * (double)ymapr[i] * (double)d);
+    out[i] = df1dx * df2dy - df1dy * df2dx;
+    return true;
+  });
+  *fdefined = classify(bad, n - 2 * nx);
+  fill_edges(nx, ny, out);
+  return 1;
+}
+
+namespace {
+// FieldCalculations.cc:2374-2378 / :2410-2414: keep |f| away from zero
+inline float clamp_coriolis(float fcor, float fcormin, float fcormax)
+{
+  if (fcor >= 0. && fcor < fcormin)
+    return fcormin;
+  if (fcor <= 0. && fcor > fcormax)
+    return fcormax;
+  return fcor;
+}
+} // namespace
+
+// FieldCalculations.cc:2351-2385 (pointwise despite the name)
+int mifcorc_momentumXcoordinate(int nx, int ny, const float* v, const float* xmapr, const float* fcoriolis, float fcoriolisMin, float* mxy, int* fdefined,
+                                float undef)
+{
+  if (nx < 3 || ny < 3)
+    return 0;
+  const int n = nx * ny;
+  const float fcormin = fabsf(fcoriolisMin), fcormax = -fcormin;
+  const bool all = (*fdefined == ALL_DEFINED);
+  size_t bad = 0;
+  for (int i = 0; i < n; ++i) {
+    if (all || defined1(v[i], undef)) {
+      const float fcor = clamp_coriolis(fcoriolis[i], fcormin, fcormax);
+      mxy[i] = float(i % nx) + v[i] * xmapr[i] / fcor;
+    } else {
+      mxy[i] = undef;
+      bad += 1;
+    }
+  }
+  *fdefined = classify(bad, n);
+  return 1;
+}
+
+// FieldCalculations.cc:2387-2422
+int mifcorc_momentumYcoordinate(int nx, int ny, const float* u, const float* ymapr, const float* fcoriolis, float fcoriolisMin, float* nxy, int* fdefined,
+                                float undef)
+{
+  if (nx < 3 || ny < 3)
+    return 0;
+  const int n = nx * ny;
+  const float fcormin = fabsf(fcoriolisMin), fcormax = -fcormin;
+  const bool all = (*fdefined == ALL_DEFINED);
+  size_t bad = 0;
+  for (int i = 0; i < n; ++i) {
+    if (all || defined1(u[i], undef)) {
+      const float fcor = clamp_coriolis(fcoriolis[i], fcormin, fcormax);
+      nxy[i] = float(i / nx) - u[i] * ymapr[i] / fcor;
+    } else {
+      nxy[i] = undef;
+      bad += 1;
+    }
+  }
+  *fdefined = classify(bad, n);
+  return 1;
+}
+
+// FieldCalculations.cc:2266-2309.  Two passes: |grad T| (gradient compute 3, which
+// also updates fDefined and fills its edges), then a stencil over T and |grad T|.
+// The second pass decides "all defined" from the flag the FIRST pass returned.
+int mifcorc_thermalFrontParameter(int nx, int ny, const float* tx, const float* xmapr, const float* ymapr, float* tfp, int* fdefined, float undef)
+{
+  const int n = nx * ny;
+  float* absdelt = new float[n > 0 ? n : 1];
+  if (!mifcorc_gradient(nx, ny, tx, xmapr, ymapr, 3, absdelt, fdefined, undef)) {
+    delete[] absdelt;
+    return 0;
+  }
+  const bool all = (*fdefined == ALL_DEFINED);
+  const size_t bad = flat_loop(nx, n - nx, [&](int i) {
+    const bool ok = (all || (defined1(tx[i - nx], undef) && defined1(tx[i - 1], undef) && defined1(tx[i + 1], undef) && defined1(tx[i + nx], undef) &&
+                             defined1(absdelt[i - nx], undef) && defined1(absdelt[i - 1], undef) && defined1(absdelt[i], undef) &&
+                             defined1(absdelt[i + 1], undef) && defined1(absdelt[i + nx], undef))) &&
+                    absdelt[i] != 0;
+    if (!ok) {
+      tfp[i] = undef;
+      return false;
+    }
+    const float gax = absdelt[i + 1] - absdelt[i - 1], gay = absdelt[i + nx] - absdelt[i - nx];
+    const float tdx = tx[i + 1] - tx[i - 1], tdy = tx[i + nx] - tx[i - nx];
+    const float dabsdeltdx = (float)(0.5 * (double)xmapr[i] * (double)gax);
+    const float dabsdeltdy = (float)(0.5 * (double)ymapr[i] * (double)gay);
+    const float dtdxa = (float)(0.5 * (double)xmapr[i] * (double)tdx / (double)absdelt[i]);
+    const float dtdya = (float)(0.5 * (double)ymapr[i] * (double)tdy / (double)absdelt[i]);
+    tfp[i] = -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya);
+    return true;
+  });
+  *fdefined = classify(bad, n - 2 * nx);
+  fill_edges(nx, ny, tfp);
+  delete[] absdelt;
+  return 1;
+}
+
 } // extern "C"

@@ -62,6 +62,17 @@ int ORC(alevelhum)(int nx, int ny, const float* t, const float* huminp, const fl
                    float undef);
 int ORC(cvhum)(int nx, int ny, const float* t, const float* huminp, const char* unit, int compute, float* humout, int* fdefined, float undef);
 
+/* FieldCalculations.cc:1942 advection, :2424 jacobian, :2351/:2387 momentum coordinates, :2266 thermalFrontParameter */
+int ORC(advection)(int nx, int ny, const float* f, const float* u, const float* v, const float* xmapr, const float* ymapr, float hours, float* advec,
+                   int* fdefined, float undef);
+int ORC(jacobian)(int nx, int ny, const float* field1, const float* field2, const float* xmapr, const float* ymapr, float* fjacobian, int* fdefined,
+                  float undef);
+int ORC(momentumXcoordinate)(int nx, int ny, const float* v, const float* xmapr, const float* fcoriolis, float fcoriolisMin, float* mxy, int* fdefined,
+                             float undef);
+int ORC(momentumYcoordinate)(int nx, int ny, const float* u, const float* ymapr, const float* fcoriolis, float fcoriolisMin, float* nxy, int* fdefined,
+                             float undef);
+int ORC(thermalFrontParameter)(int nx, int ny, const float* tx, const float* xmapr, const float* ymapr, float* tfp, int* fdefined, float undef);
+
 /* identification string: "restatement" or "reference <version>" */
 const char* ORC(kind)(void);
 

@@ -142,6 +142,40 @@ int mifcref_cvhum(int nx, int ny, const float* t, const float* huminp, const cha
   return fc::cvhum(nx, ny, t, huminp, std::string(unit), compute, humout, f.v, undef);
 }
 
+int mifcref_advection(int nx, int ny, const float* f_, const float* u, const float* v, const float* xmapr, const float* ymapr, float hours, float* advec,
+                      int* fdefined, float undef)
+{
+  Flag f(fdefined);
+  return fc::advection(nx, ny, f_, u, v, xmapr, ymapr, hours, advec, f.v, undef);
+}
+
+int mifcref_jacobian(int nx, int ny, const float* field1, const float* field2, const float* xmapr, const float* ymapr, float* fjacobian, int* fdefined,
+                     float undef)
+{
+  Flag f(fdefined);
+  return fc::jacobian(nx, ny, field1, field2, xmapr, ymapr, fjacobian, f.v, undef);
+}
+
+int mifcref_momentumXcoordinate(int nx, int ny, const float* v, const float* xmapr, const float* fcoriolis, float fcoriolisMin, float* mxy, int* fdefined,
+                                float undef)
+{
+  Flag f(fdefined);
+  return fc::momentumXcoordinate(nx, ny, v, xmapr, fcoriolis, fcoriolisMin, mxy, f.v, undef);
+}
+
+int mifcref_momentumYcoordinate(int nx, int ny, const float* u, const float* ymapr, const float* fcoriolis, float fcoriolisMin, float* nxy, int* fdefined,
+                                float undef)
+{
+  Flag f(fdefined);
+  return fc::momentumYcoordinate(nx, ny, u, ymapr, fcoriolis, fcoriolisMin, nxy, f.v, undef);
+}
+
+int mifcref_thermalFrontParameter(int nx, int ny, const float* tx, const float* xmapr, const float* ymapr, float* tfp, int* fdefined, float undef)
+{
+  Flag f(fdefined);
+  return fc::thermalFrontParameter(nx, ny, tx, xmapr, ymapr, tfp, f.v, undef);
+}
+
 #define MIFC_STR0(x) #x
 #define MIFC_STR(x) MIFC_STR0(x)
 const char* mifcref_kind(void)

@@ -53,6 +53,12 @@ def stencil_cases(grids=GRIDS_STENCIL, modes=MODES):
         cases.append(dict(base, op="plevelgwind_ycomp", args=[z_, xm, ym, fc], label="gwindy-" + lab))
         cases.append(dict(base, op="plevelgvort", args=[z_, xm, ym, fc], label="gvort-" + lab))
         cases.append(dict(base, op="ilevelgwind", args=[z_, xm, ym, fc], label="igwind-" + lab))
+        # SURVEY.md 8f-1
+        cases.append(dict(base, op="advection", args=[z_, u_, v_, xm, ym, 1.0 / 3600.0], label="advection-" + lab))
+        cases.append(dict(base, op="jacobian", args=[z_, u_, xm, ym], label="jacobian-" + lab))
+        cases.append(dict(base, op="thermalFrontParameter", args=[z_, xm, ym], label="tfp-" + lab))
+        cases.append(dict(base, op="momentumXcoordinate", args=[v_, xm, fc, 2.0e-5], label="momx-" + lab))
+        cases.append(dict(base, op="momentumYcoordinate", args=[u_, ym, fc, -3.0e-5], label="momy-" + lab))
     # invalid sizes / compute -> the operator returns false
     xm, ym, fc = synth.grid_maps(4, 2)
     u, v = synth.wind(4, 2, 1)

@@ -44,6 +44,12 @@ SIGS = {
     "hlevelhum": "pppffsio",
     "alevelhum": "pppsio",
     "cvhum": "ppsio",
+    # SURVEY.md 8f-1
+    "advection": "pppppfo",
+    "jacobian": "ppppo",
+    "momentumXcoordinate": "pppfo",
+    "momentumYcoordinate": "pppfo",
+    "thermalFrontParameter": "pppo",
 }
 _CT = {"p": _F, "o": _F, "f": _R, "s": _S, "i": _I}
 

@@ -28,7 +28,7 @@ def built():
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "mifc.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mifc_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(mifc_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol(built):

@@ -20,7 +20,7 @@ def _check(oracle, ref, case):
     outs_r = out_r if isinstance(out_r, tuple) else (out_r,)
     outs_o = out_o if isinstance(out_o, tuple) else (out_o,)
     for a, b in zip(outs_o, outs_r):
-        if not cases.same_bits(a, b):
+        if not cases.same_bits(a, b, nan_payload=False):  # NaN sign/payload of an arithmetic NaN depends on instruction selection
             bad = np.nonzero(a.view(np.uint32) != b.view(np.uint32))
             raise AssertionError("%s: %d cells differ, first at %s: oracle %r ref %r" % (
                 case["label"], len(bad[0]), (bad[0][0], bad[1][0]), a[bad][0], b[bad][0]))
