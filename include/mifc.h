@@ -132,6 +132,10 @@ int mifc_momentumYcoordinate(mifc_ctx* ctx, int nx, int ny, const float* u, cons
 /* thermalFrontParameter .h:225 / .cc:2266 (two passes: |grad T|, then the front parameter) */
 int mifc_thermalFrontParameter(mifc_ctx* ctx, int nx, int ny, const float* tx, const float* xmapr, const float* ymapr, float* tfp, int* fdefined,
                                float undef, int memkind);
+/* plevelqvector .h:122 / .cc:505 (three passes: geostrophic wind x, y, then the Q-vector component;
+ * compute 1/2 = x component from T / theta, 3/4 = y component) */
+int mifc_plevelqvector(mifc_ctx* ctx, int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr,
+                       const float* fcoriolis, float p, int compute, float* qcomp, int* fdefined, float undef, int memkind);
 
 /* ---- batched over vertical levels / ensemble members (new surface) ------ */
 /* The reference is called once per 2-D field; a caller that wants vorticity

@@ -241,6 +241,9 @@ class Context:
     def thermalFrontParameter(self, tx, xmapr, ymapr, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
         return self._single("mifc_thermalFrontParameter", [tx, xmapr, ymapr], [], [out], fdefined, undef)
 
+    def plevelqvector(self, z, t, xmapr, ymapr, fcoriolis, p, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_plevelqvector", [z, t, xmapr, ymapr, fcoriolis], [float(p), int(compute)], [out], fdefined, undef)
+
     # ------------------------------------------------------------------ batched
     def vortdiv_levels(self, u, v, xmapr, ymapr, fdefined=None, undef=UNDEF, rvort=None, diverg=None, want=("rvort", "diverg")):
         """Fused relvort + divergence over u, v of shape (nlev, ny, nx).

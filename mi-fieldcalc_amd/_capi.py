@@ -65,6 +65,7 @@ SIGNATURES = {
     "mifc_momentumXcoordinate": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "p", "pi", "f", "i"]),
     "mifc_momentumYcoordinate": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "p", "pi", "f", "i"]),
     "mifc_thermalFrontParameter": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_plevelqvector": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "f", "i", "p", "pi", "f", "i"]),
     # batched
     "mifc_vortdiv_levels": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_stencil_levels": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),

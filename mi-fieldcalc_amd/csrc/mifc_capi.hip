@@ -258,7 +258,8 @@ struct StencilCall
   const float *f0, *f1, *xm, *ym, *fc;
   float *o0, *o1;
   const float* f2; // third input field (advection)
-  float scale;     // advection
+  float scale;     // advection, Q-vector
+  float scale2;    // Q-vector
 };
 
 // count range of the raw loop -> what the flag is classified against
@@ -294,6 +295,7 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
   P.out1 = stage_out(c, 6, sc.o1, nb, memkind, &ok);
   P.f2 = stage_in(c, 7, sc.f2, nb, memkind, &ok);
   P.scale = sc.scale;
+  P.scale2 = sc.scale2;
   if (!ok || !ensure_levels(c, (size_t)sc.nlev))
     return 0;
   if (sc.op == mifc::ST_VORTDIV && !P.out0 && P.out1) {
@@ -318,10 +320,9 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
   }
   // the second pass of thermalFrontParameter rejects cells (|grad T| == 0) even
   // when its input flag is ALL_DEFINED: it always runs the counting variant
-  const bool flags_say_all = every_all;
-  if (sc.op == mifc::ST_TFP)
+  // (and so does the last pass of plevelqvector, :570)
+  if (sc.op == mifc::ST_TFP || sc.op == mifc::ST_QVEC_X || sc.op == mifc::ST_QVEC_Y)
     every_all = false;
-  (void)flags_say_all;
   P.every_level_all_defined = every_all ? 1 : 0;
   P.all_defined = c->d_flags;
   if (!every_all) {
@@ -900,6 +901,57 @@ int mifc_thermalFrontParameter(mifc_ctx* c, int nx, int ny, const float* tx, con
   if (!run_stencil(c, pass2, fdefined, undef, MIFC_MEM_DEVICE))
     return 0;
   if (!fetch_out(c, 5, tfp, n, memkind))
+    return 0;
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  return 1;
+}
+
+// plevelqvector, FieldCalculations.cc:505-595: geostrophic wind x and y into
+// the context's scratch, then the Q-vector component.  The flag threads through
+// the three passes like the reference's fDefined: the x pass leaves NONE_DEFINED
+// (:664), so the y pass always tests; the last pass tests whatever it is handed.
+int mifc_plevelqvector(mifc_ctx* c, int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr, const float* fcoriolis,
+                       float p, int compute, float* qcomp, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  if (p <= 0.0 || nx < 3 || ny < 3) // :526-530
+    return 0;
+  float tscale;
+  if (compute == 1 || compute == 3) {
+    tscale = 1.0f;
+  } else if (compute == 2 || compute == 4) {
+    const float pi = K_CP * powf(p / 1000.0f, 287.f / K_CP); // :539, host powf like the reference
+    tscale = pi / K_CP;
+  } else {
+    return 0;
+  }
+  const size_t n = (size_t)nx * ny;
+  bool ok = true;
+  const float* d_z = stage_in(c, 0, z, n, memkind, &ok);
+  const float* d_t = stage_in(c, 1, t, n, memkind, &ok);
+  const float* d_xm = stage_in(c, 2, xmapr, n, memkind, &ok);
+  const float* d_ym = stage_in(c, 3, ymapr, n, memkind, &ok);
+  const float* d_fc = stage_in(c, 4, fcoriolis, n, memkind, &ok);
+  float* d_out = stage_out(c, 5, qcomp, n, memkind, &ok);
+  if (!ok || !ensure_slot(c, 8, n * sizeof(float)) || !ensure_slot(c, 9, n * sizeof(float)))
+    return 0;
+  float* d_ug = static_cast<float*>(c->slot[8]);
+  float* d_vg = static_cast<float*>(c->slot[9]);
+  const StencilCall pass1 = {mifc::ST_GWIND_X, nx, ny, 1, d_z, nullptr, d_xm, d_ym, d_fc, d_ug, nullptr};
+  if (!run_stencil(c, pass1, fdefined, undef, MIFC_MEM_DEVICE))
+    return 0;
+  const StencilCall pass2 = {mifc::ST_GWIND_Y, nx, ny, 1, d_z, nullptr, d_xm, d_ym, d_fc, d_vg, nullptr};
+  if (!run_stencil(c, pass2, fdefined, undef, MIFC_MEM_DEVICE))
+    return 0;
+  StencilCall pass3 = {compute < 3 ? mifc::ST_QVEC_X : mifc::ST_QVEC_Y, nx, ny, 1, d_ug, d_vg, d_xm, d_ym, nullptr, d_out, nullptr};
+  pass3.f2 = d_t;
+  pass3.scale = tscale;
+  pass3.scale2 = (float)((double)(-287.f) / ((double)p * 100.)); // :564
+  if (!run_stencil(c, pass3, fdefined, undef, MIFC_MEM_DEVICE))
+    return 0;
+  if (!fetch_out(c, 5, qcomp, n, memkind))
     return 0;
   MIFC_HIP(c, hipStreamSynchronize(c->stream));
   return 1;

@@ -93,7 +93,10 @@ enum StencilOp {
   // SURVEY.md 8f-1 (one-lane-per-cell kernel only, so far)
   ST_ADVECTION = 12, // advection :1942: f0 = f, f1 = u, f2 = v, scale = -3600*hours
   ST_JACOBIAN = 13,  // jacobian :2424: f0 = field1, f1 = field2
-  ST_TFP = 14        // second pass of thermalFrontParameter :2289-2302: f0 = tx, f1 = |grad tx|
+  ST_TFP = 14,       // second pass of thermalFrontParameter :2289-2302: f0 = tx, f1 = |grad tx|
+  // last pass of plevelqvector :564-593: f0 = ug, f1 = vg, f2 = t, scale = tscale, scale2 = c
+  ST_QVEC_X = 15, // compute 1, 2
+  ST_QVEC_Y = 16  // compute 3, 4
 };
 
 struct StencilParams
@@ -108,7 +111,8 @@ struct StencilParams
   const float* f0; // u | z | field | mpot
   const float* f1; // v (uv family only)
   const float* f2; // third input (advection: v)
-  float scale;     // advection: -3600 * hours, rounded to float like the reference (:1963)
+  float scale;     // advection: -3600 * hours, rounded to float like the reference (:1963); Q-vector: tscale
+  float scale2;    // Q-vector: c = -r / (p * 100) (:564)
   const float* xmapr;
   const float* ymapr;
   const float* fcoriolis;

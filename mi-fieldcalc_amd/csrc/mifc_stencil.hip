@@ -100,6 +100,30 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
     o.o0 = -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya);
     return true;
   }
+  if (OP == ST_QVEC_X || OP == ST_QVEC_Y) { // :570-584; "!= undef" only (no NaN test), whatever the input flag says
+    const float* ug = f0;
+    const float* vg = f1;
+    const float* t = P.f2 + (size_t)blockIdx.y * P.in_level_stride;
+    const float us = ug[p - nx], uw = ug[p - 1], ue = ug[p + 1], un = ug[p + nx];
+    const float vs = vg[p - nx], vw = vg[p - 1], ve = vg[p + 1], vn = vg[p + nx];
+    const float ts = t[p - nx], tw = t[p - 1], te = t[p + 1], tn = t[p + nx];
+    if (!(us != undef && uw != undef && ue != undef && un != undef && vs != undef && vw != undef && ve != undef && vn != undef && ts != undef &&
+          tw != undef && te != undef && tn != undef))
+      return false;
+    const double hx = 0.5 * (double)P.xmapr[p], hy = 0.5 * (double)P.ymapr[p];
+    const float dtdx = (float)(hx * (double)P.scale * (double)(te - tw));
+    const float dtdy = (float)(hy * (double)P.scale * (double)(tn - ts));
+    if (OP == ST_QVEC_X) {
+      const float dugdx = (float)(hx * (double)(ue - uw));
+      const float dvgdx = (float)(hx * (double)(ve - vw));
+      o.o0 = P.scale2 * (dugdx * dtdx + dvgdx * dtdy);
+    } else {
+      const float dugdy = (float)(hy * (double)(un - us));
+      const float dvgdy = (float)(hy * (double)(vn - vs));
+      o.o0 = P.scale2 * (dugdy * dtdx + dvgdy * dtdy);
+    }
+    return true;
+  }
   const float* f = f0;
   if (OP == ST_GRAD_X) { // :2015-2016
     const float w = f[p - 1], e = f[p + 1];
@@ -184,7 +208,8 @@ __global__ __launch_bounds__(256) void stencil_cell_kernel(const StencilParams P
     if ((OP == ST_VORTDIV || OP == ST_IGWIND) && out1)
       out1[i] = o.o1;
 
-    if (CHECK && (!all || OP == ST_TFP)) { // TFP rejects |grad T| == 0 cells whatever the input flag says
+    // TFP rejects |grad T| == 0 cells, the Q-vector pass tests its inputs, whatever the input flag says
+    if (CHECK && (!all || OP == ST_TFP || OP == ST_QVEC_X || OP == ST_QVEC_Y)) {
       // Count over the raw loop range, with the wrapped neighbours the flat
       // loop sees at the edge columns (Appendix A #6).
       const long gi = (long)j * nx + c;
@@ -282,6 +307,10 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
     return launch_cell<ST_JACOBIAN>(prm, stream);
   case ST_TFP:
     return launch_cell<ST_TFP>(prm, stream);
+  case ST_QVEC_X:
+    return launch_cell<ST_QVEC_X>(prm, stream);
+  case ST_QVEC_Y:
+    return launch_cell<ST_QVEC_Y>(prm, stream);
   default:
     return hipErrorInvalidValue;
   }

@@ -111,6 +111,8 @@ bool momentumYcoordinate(int nx, int ny, const float* u, const float* ymapr, con
                          float* nxy, ValuesDefined& fDefined, float undef);
 bool thermalFrontParameter(int nx, int ny, const float* t, const float* xmapr, const float* ymapr,
                            float* tfp, ValuesDefined& fDefined, float undef);
+bool plevelqvector(int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr, const float* fcoriolis,
+                   float p, int compute, float* qcomp, ValuesDefined& fDefined, float undef);
 
 // ---- extensions of this implementation (not in the reference) -----------------
 // Fused relvort + divergence for nlev levels stored [nlev][ny][nx]; xmapr/ymapr

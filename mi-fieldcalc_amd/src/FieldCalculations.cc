@@ -207,6 +207,13 @@ bool thermalFrontParameter(int nx, int ny, const float* t, const float* xmapr, c
   return mifc_thermalFrontParameter(context(), nx, ny, t, xmapr, ymapr, tfp, f.ptr(), undef, MIFC_MEM_HOST) != 0;
 }
 
+bool plevelqvector(int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr, const float* fcoriolis, float p,
+                   int compute, float* qcomp, ValuesDefined& fDefined, float undef)
+{
+  FlagIO f(fDefined);
+  return mifc_plevelqvector(context(), nx, ny, z, t, xmapr, ymapr, fcoriolis, p, compute, qcomp, f.ptr(), undef, MIFC_MEM_HOST) != 0;
+}
+
 bool vortdiv_levels(int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr, float* rvort, float* diverg,
                     std::vector<ValuesDefined>& fDefined, float undef)
 {

@@ -970,4 +970,60 @@ int mifcorc_thermalFrontParameter(int nx, int ny, const float* tx, const float* 
   return 1;
 }
 
+// FieldCalculations.cc:505-595.  plevelgwind_xcomp leaves fDefined = NONE_DEFINED
+// (:664), so the y component always runs with its tests switched on; the last
+// pass tests with "!= undef" only (no NaN test) and ignores the input flag.
+int mifcorc_plevelqvector(int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr, const float* fcoriolis, float p,
+                          int compute, float* qcomp, int* fdefined, float undef)
+{
+  if (p <= 0.0)
+    return 0;
+  if (nx < 3 || ny < 3)
+    return 0;
+  float tscale;
+  if (compute == 1 || compute == 3) {
+    tscale = 1.0;
+  } else if (compute == 2 || compute == 4) {
+    const float pi = K_CP * powf(p / K_P0, K_R / K_CP); // :538
+    tscale = pi / K_CP;
+  } else {
+    return 0;
+  }
+  const int n = nx * ny;
+  float* ug = new float[n];
+  float* vg = new float[n];
+  int ok = mifcorc_plevelgwind_xcomp(nx, ny, z, xmapr, ymapr, fcoriolis, ug, fdefined, undef) &&
+           mifcorc_plevelgwind_ycomp(nx, ny, z, xmapr, ymapr, fcoriolis, vg, fdefined, undef);
+  if (ok) {
+    const float c = (float)((double)(-K_R) / ((double)p * 100.));
+    const size_t bad = flat_loop(nx, n - nx, [&](int i) {
+      if (!(ug[i - nx] != undef && ug[i - 1] != undef && ug[i + 1] != undef && ug[i + nx] != undef && vg[i - nx] != undef && vg[i - 1] != undef &&
+            vg[i + 1] != undef && vg[i + nx] != undef && t[i - nx] != undef && t[i - 1] != undef && t[i + 1] != undef && t[i + nx] != undef)) {
+        qcomp[i] = undef;
+        return false;
+      }
+      const float tdx = t[i + 1] - t[i - 1], tdy = t[i + nx] - t[i - nx];
+      const float dtdx = (float)(0.5 * (double)xmapr[i] * (double)tscale * (double)tdx);
+      const float dtdy = (float)(0.5 * (double)ymapr[i] * (double)tscale * (double)tdy);
+      if (compute < 3) {
+        const float a = ug[i + 1] - ug[i - 1], b = vg[i + 1] - vg[i - 1];
+        const float dugdx = (float)(0.5 * (double)xmapr[i] * (double)a);
+        const float dvgdx = (float)(0.5 * (double)xmapr[i] * (double)b);
+        qcomp[i] = c * (dugdx * dtdx + dvgdx * dtdy);
+      } else {
+        const float a = ug[i + nx] - ug[i - nx], b = vg[i + nx] - vg[i - nx];
+        const float dugdy = (float)(0.5 * (double)ymapr[i] * (double)a);
+        const float dvgdy = (float)(0.5 * (double)ymapr[i] * (double)b);
+        qcomp[i] = c * (dugdy * dtdx + dvgdy * dtdy);
+      }
+      return true;
+    });
+    *fdefined = classify(bad, n - 2 * nx);
+    fill_edges(nx, ny, qcomp);
+  }
+  delete[] ug;
+  delete[] vg;
+  return ok;
+}
+
 } // extern "C"

@@ -72,6 +72,9 @@ int ORC(momentumXcoordinate)(int nx, int ny, const float* v, const float* xmapr,
 int ORC(momentumYcoordinate)(int nx, int ny, const float* u, const float* ymapr, const float* fcoriolis, float fcoriolisMin, float* nxy, int* fdefined,
                              float undef);
 int ORC(thermalFrontParameter)(int nx, int ny, const float* tx, const float* xmapr, const float* ymapr, float* tfp, int* fdefined, float undef);
+/* FieldCalculations.cc:505 plevelqvector (three passes: geostrophic wind x, y, then the Q-vector component) */
+int ORC(plevelqvector)(int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr, const float* fcoriolis, float p,
+                       int compute, float* qcomp, int* fdefined, float undef);
 
 /* identification string: "restatement" or "reference <version>" */
 const char* ORC(kind)(void);

@@ -176,6 +176,13 @@ int mifcref_thermalFrontParameter(int nx, int ny, const float* tx, const float* 
   return fc::thermalFrontParameter(nx, ny, tx, xmapr, ymapr, tfp, f.v, undef);
 }
 
+int mifcref_plevelqvector(int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr, const float* fcoriolis, float p,
+                          int compute, float* qcomp, int* fdefined, float undef)
+{
+  Flag f(fdefined);
+  return fc::plevelqvector(nx, ny, z, t, xmapr, ymapr, fcoriolis, p, compute, qcomp, f.v, undef);
+}
+
 #define MIFC_STR0(x) #x
 #define MIFC_STR(x) MIFC_STR0(x)
 const char* mifcref_kind(void)

@@ -59,6 +59,9 @@ def stencil_cases(grids=GRIDS_STENCIL, modes=MODES):
         cases.append(dict(base, op="thermalFrontParameter", args=[z_, xm, ym], label="tfp-" + lab))
         cases.append(dict(base, op="momentumXcoordinate", args=[v_, xm, fc, 2.0e-5], label="momx-" + lab))
         cases.append(dict(base, op="momentumYcoordinate", args=[u_, ym, fc, -3.0e-5], label="momy-" + lab))
+        tq = (250.0 + 0.05 * (z_ - 5500.0)).astype(np.float32) if mode in ("all",) else np.where((z_ == UNDEF) | np.isnan(z_), z_, 250.0 + 0.05 * (z_ - 5500.0)).astype(np.float32)
+        for c in (0, 1, 2, 3, 4, 5):
+            cases.append(dict(base, op="plevelqvector", args=[z_, tq, xm, ym, fc, 500.0, c], label="qvector%d-%s" % (c, lab)))
     # invalid sizes / compute -> the operator returns false
     xm, ym, fc = synth.grid_maps(4, 2)
     u, v = synth.wind(4, 2, 1)
@@ -66,6 +69,7 @@ def stencil_cases(grids=GRIDS_STENCIL, modes=MODES):
     xm, ym, fc = synth.grid_maps(5, 4)
     z = synth.scalar_field(5, 4, 3)
     cases.append(dict(op="gradient", nx=5, ny=4, args=[z, xm, ym, 5], fdefined=SOME_DEFINED, undef=UNDEF, label="gradient-bad-compute"))
+    cases.append(dict(op="plevelqvector", nx=5, ny=4, args=[z, z, xm, ym, fc, 0.0, 1], fdefined=SOME_DEFINED, undef=UNDEF, label="qvector-bad-p"))
     return cases
 
 

@@ -50,6 +50,7 @@ SIGS = {
     "momentumXcoordinate": "pppfo",
     "momentumYcoordinate": "pppfo",
     "thermalFrontParameter": "pppo",
+    "plevelqvector": "pppppfio",
 }
 _CT = {"p": _F, "o": _F, "f": _R, "s": _S, "i": _I}
 
