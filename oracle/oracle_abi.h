@@ -76,6 +76,66 @@ int ORC(thermalFrontParameter)(int nx, int ny, const float* tx, const float* xma
 int ORC(plevelqvector)(int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr, const float* fcoriolis, float p,
                        int compute, float* qcomp, int* fdefined, float undef);
 
+/* ---- the rest of the pointwise catalogue (FieldCalculations.cc line of each in the comment) ---- */
+/* :369, :1100, :1355 */
+int ORC(plevelthe)(int nx, int ny, const float* t, const float* rh, float p, int compute, float* the, int* fdefined, float undef);
+int ORC(hlevelthe)(int nx, int ny, const float* t, const float* q, const float* ps, float alevel, float blevel, int compute, float* the, int* fdefined,
+                   float undef);
+int ORC(alevelthe)(int nx, int ny, const float* t, const float* q, const float* p, int compute, float* the, int* fdefined, float undef);
+/* :597, :1219, :1460, :1276, :466 */
+int ORC(plevelducting)(int nx, int ny, const float* t, const float* h, float p, int compute, float* duct, int* fdefined, float undef);
+int ORC(hlevelducting)(int nx, int ny, const float* t, const float* h, const float* ps, float alevel, float blevel, int compute, float* duct,
+                       int* fdefined, float undef);
+int ORC(alevelducting)(int nx, int ny, const float* t, const float* h, const float* p, int compute, float* duct, int* fdefined, float undef);
+int ORC(hlevelpressure)(int nx, int ny, const float* ps, float alevel, float blevel, float* p, int* fdefined, float undef);
+int ORC(pleveldz2tmean)(int nx, int ny, const float* z1, const float* z2, float p1, float p2, int compute, float* tmean, int* fdefined, float undef);
+/* :745, :816, :872, :973, :1016 */
+int ORC(kIndex)(int nx, int ny, const float* t500, const float* t700, const float* rh700, const float* t850, const float* rh850, float p500, float p700,
+                float p850, int compute, float* kfield, int* fdefined, float undef);
+int ORC(ductingIndex)(int nx, int ny, const float* t850, const float* rh850, float p850, int compute, float* duct, int* fdefined, float undef);
+int ORC(showalterIndex)(int nx, int ny, const float* t500, const float* t850, const float* rh850, float p500, float p850, int compute, float* sfield,
+                        int* fdefined, float undef);
+int ORC(boydenIndex)(int nx, int ny, const float* t700, const float* z700, const float* z1000, float p700, float p1000, int compute, float* bfield,
+                     int* fdefined, float undef);
+int ORC(sweatIndex)(int nx, int ny, const float* t850, const float* t500, const float* td850, const float* td500, const float* u850, const float* v850,
+                    const float* u500, const float* v500, float* sindex, int* fdefined, float undef);
+/* :1555, :1608, :1676, :2181, :2231, :2311, :3063, :2462 */
+int ORC(seaSoundSpeed)(int nx, int ny, const float* t, const float* s, float z, int compute, float* soundspeed, int* fdefined, float undef);
+int ORC(cvtemp)(int nx, int ny, const float* tinp, int compute, float* tout, int* fdefined, float undef);
+int ORC(abshum)(int nx, int ny, const float* t, const float* rhum, float* abshumout, int* fdefined, float undef);
+int ORC(windCooling)(int nx, int ny, const float* t, const float* u, const float* v, int compute, float* dtcool, int* fdefined, float undef);
+int ORC(underCooledRain)(int nx, int ny, const float* precip, const float* snow, const float* tk, float precipMin, float snowRateMax, float tcMax,
+                         float* undercooled, int* fdefined, float undef);
+int ORC(pressure2FlightLevel)(int nx, int ny, const float* pressure, float* flightlevel, int* fdefined, float undef);
+int ORC(snow_in_cm)(int nx, int ny, const float* snow_water, const float* tk2m, const float* td2m, float* snow_cm, int* fdefined, float undef);
+/* the reference takes std::vector<float> values; here pointer + length */
+int ORC(values2classes)(int nx, int ny, const float* fvalue, float* fclass, const float* values, int nvalues, int* fdefined, float undef);
+/* field algebra :2501-2669 (the reference's void functions return 1 here) */
+int ORC(minvalueFields)(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef);
+int ORC(maxvalueFields)(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef);
+int ORC(minvalueFieldConst)(int nx, int ny, const float* field1, float value, float* fres, int* fdefined, float undef);
+int ORC(maxvalueFieldConst)(int nx, int ny, const float* field1, float value, float* fres, int* fdefined, float undef);
+int ORC(absvalueField)(int nx, int ny, const float* field, float* fres, int* fdefined, float undef);
+int ORC(log10Field)(int nx, int ny, const float* field, float* fres, int* fdefined, float undef);
+int ORC(pow10Field)(int nx, int ny, const float* field, float* fres, int* fdefined, float undef);
+int ORC(logField)(int nx, int ny, const float* field, float* fres, int* fdefined, float undef);
+int ORC(expField)(int nx, int ny, const float* field, float* fres, int* fdefined, float undef);
+int ORC(powerField)(int nx, int ny, const float* field, float value, float* fres, int* fdefined, float undef);
+int ORC(replaceUndefined)(int nx, int ny, const float* field, float value, float* fres, int* fdefined, float undef);
+int ORC(replaceDefined)(int nx, int ny, const float* field, float value, float* fres, int* fdefined, float undef);
+int ORC(fieldOPERfield)(int compute, int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef);
+int ORC(fieldOPERconstant)(int compute, int nx, int ny, const float* field, float value, float* fres, int* fdefined, float undef);
+int ORC(constantOPERfield)(int compute, int nx, int ny, float value, const float* field, float* fres, int* fdefined, float undef);
+
+/* ---- ensemble reductions :2671-2860 (std::vector<float*> -> pointer table + length,
+ *      std::vector<ValuesDefined> -> int array of the same length) ---- */
+int ORC(sumFields)(int nx, int ny, const float* const* fields, int nfields, float* fres, int* fdefined, float undef);
+int ORC(meanValue)(int nx, int ny, const float* const* fields, const int* fdefined_in, int nfields, float* fres, int* fdefined_out, float undef);
+int ORC(stddevValue)(int nx, int ny, const float* const* fields, const int* fdefined_in, int nfields, float* fres, int* fdefined_out, float undef);
+int ORC(extremeValue)(int compute, int nx, int ny, const float* const* fields, int nfields, float* fres, int* fdefined, float undef);
+int ORC(probability)(int compute, int nx, int ny, const float* const* fields, const int* fdefined_in, int nfields, const float* limits, int nlimits,
+                     float* fres, int* fdefined_out, float undef);
+
 /* identification string: "restatement" or "reference <version>" */
 const char* ORC(kind)(void);
 

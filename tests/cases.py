@@ -135,6 +135,144 @@ def ewise_cases(grids=GRIDS_EWISE, modes=MODES):
     return cases
 
 
+def catalogue_cases(grids=GRIDS_EWISE, modes=MODES):
+    """the rest of the pointwise catalogue."""
+    cases = []
+    for (nx, ny), mode in itertools.product(grids, modes):
+        seed = 313 * nx + ny
+        u, v = synth.wind(nx, ny, seed)
+        u5, v5 = synth.wind(nx, ny, seed + 1)
+        t, q, ps = synth.thermo(nx, ny, seed)
+        t = t.copy()
+        flat = t.reshape(-1)
+        if flat.size >= 8:  # outside / on the edge of the ewt table
+            flat[1] = 273.15 + 100.0
+            flat[2] = 273.15 - 100.0
+            flat[3] = 150.0
+            flat[4] = 400.0
+        shape = (ny, nx)
+        rh = synth.uniform(shape, seed + 9, 0.5, 110.0).astype(np.float32)
+        rh7 = synth.uniform(shape, seed + 12, 0.5, 110.0).astype(np.float32)
+        theta = (t * 1.05).astype(np.float32)
+        p3 = synth.uniform(shape, seed + 11, 150.0, 1040.0).astype(np.float32)
+        t5 = (t - 30.0).astype(np.float32)
+        t7 = (t - 12.0).astype(np.float32)
+        td = (t - synth.uniform(shape, seed + 10, 0.0, 25.0)).astype(np.float32)
+        td5 = (t5 - synth.uniform(shape, seed + 13, 0.0, 25.0)).astype(np.float32)
+        z7 = synth.uniform(shape, seed + 14, 2700.0, 3200.0).astype(np.float32)
+        z10 = synth.uniform(shape, seed + 15, -100.0, 250.0).astype(np.float32)
+        sal = synth.uniform(shape, seed + 16, 5.0, 38.0).astype(np.float32)
+        tsea = synth.uniform(shape, seed + 17, -1.5, 25.0).astype(np.float32)
+        precip = synth.uniform(shape, seed + 18, 0.0, 6.0).astype(np.float32)
+        snow = (precip * synth.uniform(shape, seed + 19, 0.0, 1.0)).astype(np.float32)
+        snoww = synth.uniform(shape, seed + 20, -1.0, 30.0).astype(np.float32)
+        anyf = synth.uniform(shape, seed + 21, -50.0, 50.0).astype(np.float32)
+        posf = synth.uniform(shape, seed + 22, 0.001, 500.0).astype(np.float32)
+        smallf = synth.uniform(shape, seed + 23, -8.0, 8.0).astype(np.float32)
+        zerof = np.where(synth.uniform(shape, seed + 24, 0.0, 1.0) < 0.2, 0.0, anyf).astype(np.float32)
+        fields = [u, v, u5, v5, t, q, ps, rh, rh7, theta, p3, t5, t7, td, td5, z7, z10, sal, tsea, precip, snow, snoww, anyf, posf, smallf, zerof]
+        (u_, v_, u5_, v5_, t_, q_, ps_, rh_, rh7_, th_, p3_, t5_, t7_, td_, td5_, z7_, z10_, sal_, tsea_, precip_, snow_, snoww_, anyf_, posf_,
+         smallf_, zerof_), flag = _apply_mode(fields, mode, seed, _frac(nx, ny))
+        base = dict(nx=nx, ny=ny, fdefined=flag, undef=UNDEF)
+        lab = "%dx%d-%s" % (nx, ny, mode)
+
+        def add(op, args, tag=""):
+            cases.append(dict(base, op=op, args=args, label="%s%s-%s" % (op, tag, lab)))
+
+        for c in (0, 1, 2, 3):
+            add("plevelthe", [th_ if c == 2 else t_, rh_, 850.0, c], str(c))
+            add("hlevelthe", [th_ if c == 2 else t_, q_, ps_, 12.5, 0.73, c], str(c))
+            add("alevelthe", [th_ if c == 2 else t_, q_, p3_, c], str(c))
+            add("kIndex", [t5_, t7_, rh7_, t_, rh_, 500.0, 700.0, 850.0, c], str(c))
+            add("ductingIndex", [th_ if c == 2 else t_, rh_, 850.0, c], str(c))
+            add("showalterIndex", [t5_, t_, rh_, 500.0, 850.0, c], str(c))
+            add("boydenIndex", [t7_, z7_, z10_, 700.0, 1000.0, c], str(c))
+            add("seaSoundSpeed", [tsea_ if c == 1 else (t_ if mode != "all" else (tsea + np.float32(273.15)).astype(np.float32)), sal_, -75.0, c], str(c))
+            add("windCooling", [t_ if c == 1 else tsea_, u_, v_, c], str(c))
+        for c in (0, 1, 2, 3, 4, 5):
+            hum = q_ if c in (1, 2) else rh_
+            add("plevelducting", [th_ if c % 2 == 0 else t_, hum, 925.0, c], str(c))
+            add("hlevelducting", [th_ if c % 2 == 0 else t_, hum, ps_, 12.5, 0.73, c], str(c))
+            add("alevelducting", [th_ if c % 2 == 0 else t_, hum, p3_, c], str(c))
+            add("cvtemp", [tsea_ if c in (2, 4) else t_, c], str(c))
+            add("fieldOPERfield", [c, anyf_, zerof_], str(c))
+            add("fieldOPERconstant", [c, anyf_, 2.5], str(c))
+            add("fieldOPERconstant", [c, anyf_, 0.0], "%dzero" % c)
+            add("constantOPERfield", [c, 2.5, zerof_], str(c))
+        add("cvtemp", [t_, 4], "4-looks-like-kelvin")  # mean > t0/2: input copied, flag untouched
+        add("cvtemp", [tsea_, 3], "3-looks-like-celsius")
+        add("fieldOPERconstant", [1, anyf_, float(UNDEF)], "-undef-constant")
+        add("constantOPERfield", [9, float(UNDEF), anyf_], "-undef-constant-bad-compute")
+        add("hlevelpressure", [ps_, 12.5, 0.73])
+        for c in (0, 1, 2, 3, 4):
+            add("pleveldz2tmean", [z7_, z10_, 700.0, 1000.0, c], str(c))
+        add("sweatIndex", [t_, t5_, td_, td5_, u_, v_, u5_, v5_])
+        add("abshum", [t_, rh_])
+        add("underCooledRain", [precip_, snow_, t_, 0.5, 0.3, 1.0])
+        add("pressure2FlightLevel", [p3_])
+        add("snow_in_cm", [snoww_, t_, td_])
+        add("values2classes", [anyf_, [-40.0, -10.0, 0.0, 5.0, 20.0, 45.0]])
+        add("values2classes", [anyf_, [-40.0, 45.0]], "-two")
+        add("values2classes", [anyf_, [1.0]], "-too-few")
+        add("minvalueFields", [anyf_, smallf_])
+        add("maxvalueFields", [anyf_, smallf_])
+        for val, tag in ((3.5, ""), (float(UNDEF), "-undef")):
+            add("minvalueFieldConst", [anyf_, val], tag)
+            add("maxvalueFieldConst", [anyf_, val], tag)
+            add("powerField", [posf_, 0.37 if tag == "" else val], tag)
+            add("replaceUndefined", [anyf_, val], tag)
+            add("replaceDefined", [anyf_, val], tag)
+        add("absvalueField", [anyf_])
+        add("log10Field", [posf_])
+        add("logField", [posf_])
+        add("pow10Field", [smallf_])
+        add("expField", [smallf_])
+        # the flag is an input of replaceUndefined / replaceDefined: all three values
+        for f in (ALL_DEFINED, NONE_DEFINED, SOME_DEFINED):
+            cases.append(dict(base, fdefined=f, op="replaceUndefined", args=[anyf_, -1.0], label="replaceUndefined-flag%d-%s" % (f, lab)))
+            cases.append(dict(base, fdefined=f, op="replaceDefined", args=[anyf_, -1.0], label="replaceDefined-flag%d-%s" % (f, lab)))
+    # argument validation
+    t, q, ps = synth.thermo(5, 4, 1)
+    base = dict(nx=5, ny=4, fdefined=SOME_DEFINED, undef=UNDEF)
+    cases.append(dict(base, op="plevelthe", args=[t, q, 0.0, 1], label="plevelthe-badp"))
+    cases.append(dict(base, op="plevelducting", args=[t, q, -5.0, 1], label="plevelducting-badp"))
+    cases.append(dict(base, op="kIndex", args=[t, t, q, t, q, 700.0, 700.0, 850.0, 1], label="kIndex-bad-levels"))
+    cases.append(dict(base, op="showalterIndex", args=[t, t, q, 850.0, 500.0, 1], label="showalter-bad-levels"))
+    cases.append(dict(base, op="boydenIndex", args=[t, t, t, 1000.0, 700.0, 1], label="boyden-bad-levels"))
+    cases.append(dict(base, op="ductingIndex", args=[t, q, 0.0, 1], label="ductingIndex-badp"))
+    cases.append(dict(base, op="pleveldz2tmean", args=[t, t, 500.0, 500.0, 1], label="dz2tmean-same-p"))
+    for a, b in ((-1.0, 0.5), (0.0, 0.0), (1.0, 1.5)):
+        cases.append(dict(base, op="hlevelthe", args=[t, q, ps, a, b, 1], label="hlevelthe-badlevel%g%g" % (a, b)))
+        cases.append(dict(base, op="hlevelducting", args=[t, q, ps, a, b, 1], label="hlevelducting-badlevel%g%g" % (a, b)))
+        cases.append(dict(base, op="hlevelpressure", args=[ps, a, b], label="hlevelpressure-badlevel%g%g" % (a, b)))
+    return cases
+
+
+def ensemble_cases(grids=((5, 4), (17, 9), (64, 48)), modes=MODES):
+    """reductions over ensemble members."""
+    cases = []
+    for (nx, ny), mode, nmem in itertools.product(grids, modes, (1, 3, 8)):
+        seed = 911 * nx + ny + nmem
+        members = [synth.uniform((ny, nx), seed + 7 * k, -5.0, 30.0).astype(np.float32) for k in range(nmem)]
+        members, flag = _apply_mode(members, mode, seed, 0.3 if mode != "none" else 1.0)
+        flags_in = [flag] * nmem
+        if nmem >= 3:
+            flags_in[1] = NONE_DEFINED  # probability() skips such members
+            if mode == "all":
+                flags_in[2] = SOME_DEFINED
+        base = dict(nx=nx, ny=ny, fdefined=flag, undef=UNDEF)
+        lab = "%dx%d-%s-m%d" % (nx, ny, mode, nmem)
+        cases.append(dict(base, op="sumFields", args=[members], label="sumFields-" + lab))
+        cases.append(dict(base, op="meanValue", args=[members, flags_in], label="meanValue-" + lab))
+        cases.append(dict(base, op="stddevValue", args=[members, flags_in], label="stddevValue-" + lab))
+        for c in (0, 1, 2, 3, 4):
+            cases.append(dict(base, op="extremeValue", args=[c, members], label="extremeValue%d-%s" % (c, lab)))
+        for c in (1, 2, 3, 4, 5, 6):
+            cases.append(dict(base, op="probability", args=[c, members, flags_in, [5.0, 20.0]], label="probability%d-%s" % (c, lab)))
+        cases.append(dict(base, op="probability", args=[3, members, flags_in, [5.0]], label="probability-between-one-limit-" + lab))
+    return cases
+
+
 N_OUT = {"ilevelgwind": 2}
 
 

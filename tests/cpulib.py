@@ -26,7 +26,10 @@ _I = ctypes.c_int
 _R = ctypes.c_float
 _S = ctypes.c_char_p
 
-# name -> argtypes after (nx, ny): 'p' field pointer, 'f' float, 's' string, 'i' int, 'o' output pointer
+# name -> argtypes after (nx, ny): 'p' field pointer, 'f' float, 's' string, 'i' int, 'o' output pointer,
+# 'T' table of field pointers (argument: list of arrays), 'D' int array, one per field of the table
+# (argument: list of flags), 'n' the table's length (filled in here), 'V' float array + its length
+# (argument: list of floats).  A leading 'C' = an int `compute` BEFORE (nx, ny), as the reference has it.
 SIGS = {
     "vectorabs": "ppo",
     "relvort": "ppppo",
@@ -51,8 +54,51 @@ SIGS = {
     "momentumYcoordinate": "pppfo",
     "thermalFrontParameter": "pppo",
     "plevelqvector": "pppppfio",
+    # SURVEY.md 8f-3
+    "plevelthe": "ppfio",
+    "hlevelthe": "pppffio",
+    "alevelthe": "pppio",
+    "plevelducting": "ppfio",
+    "hlevelducting": "pppffio",
+    "alevelducting": "pppio",
+    "hlevelpressure": "pffo",
+    "pleveldz2tmean": "ppffio",
+    "kIndex": "pppppfffio",
+    "ductingIndex": "ppfio",
+    "showalterIndex": "pppffio",
+    "boydenIndex": "pppffio",
+    "sweatIndex": "ppppppppo",
+    "seaSoundSpeed": "ppfio",
+    "cvtemp": "pio",
+    "abshum": "ppo",
+    "windCooling": "pppio",
+    "underCooledRain": "pppfffo",
+    "pressure2FlightLevel": "po",
+    "snow_in_cm": "pppo",
+    "values2classes": "poV",
+    "minvalueFields": "ppo",
+    "maxvalueFields": "ppo",
+    "minvalueFieldConst": "pfo",
+    "maxvalueFieldConst": "pfo",
+    "absvalueField": "po",
+    "log10Field": "po",
+    "pow10Field": "po",
+    "logField": "po",
+    "expField": "po",
+    "powerField": "pfo",
+    "replaceUndefined": "pfo",
+    "replaceDefined": "pfo",
+    "fieldOPERfield": "Cppo",
+    "fieldOPERconstant": "Cpfo",
+    "constantOPERfield": "Cfpo",
+    # SURVEY.md 8f-4
+    "sumFields": "Tno",
+    "meanValue": "TDno",
+    "stddevValue": "TDno",
+    "extremeValue": "CTno",
+    "probability": "CTDnVo",
 }
-_CT = {"p": _F, "o": _F, "f": _R, "s": _S, "i": _I}
+_CT = {"p": [_F], "o": [_F], "f": [_R], "s": [_S], "i": [_I], "T": [_F], "D": [_F], "n": [_I], "V": [_F, _I]}
 
 
 def available(which):
@@ -70,7 +116,8 @@ class CpuLib:
         for name, sig in SIGS.items():
             fn = getattr(self._lib, prefix + name)
             fn.restype = _I
-            fn.argtypes = [_I, _I] + [_CT[c] for c in sig] + [ctypes.c_void_p, _R]
+            lead = [_I] if sig.startswith("C") else []
+            fn.argtypes = lead + [_I, _I] + [t for c in sig.lstrip("C") for t in _CT[c]] + [ctypes.c_void_p, _R]
             self._fn[name] = fn
         kind = getattr(self._lib, prefix + "kind")
         kind.restype = _S
@@ -80,11 +127,15 @@ class CpuLib:
         """args in reference order (fields as numpy float32 arrays, scalars,
         strings); outputs are allocated here.  Returns (ok, out or (out0,out1), flag)."""
         sig = SIGS[name]
-        n_in = sum(1 for c in sig if c != "o")
+        lead = []
+        if sig.startswith("C"):
+            lead, args, sig = [int(args[0])], args[1:], sig[1:]
+        n_in = sum(1 for c in sig if c not in "on")
         assert len(args) == n_in, (name, len(args), n_in)
         cargs, keep = [], []
         it = iter(args)
         n_out = sig.count("o")
+        n_table = 0
         if outs is None:
             outs = [np.empty((ny, nx), dtype=np.float32) for _ in range(n_out)]
         oi = iter(outs)
@@ -99,6 +150,22 @@ class CpuLib:
                     cargs.append(a.ctypes.data)
             elif c == "o":
                 cargs.append(next(oi).ctypes.data)
+            elif c == "T":
+                fields = [np.ascontiguousarray(a, dtype=np.float32) for a in next(it)]
+                table = (ctypes.c_void_p * max(len(fields), 1))(*[a.ctypes.data for a in fields])
+                keep += fields + [table]
+                n_table = len(fields)
+                cargs.append(ctypes.addressof(table))
+            elif c == "D":
+                flags = (ctypes.c_int * max(n_table, 1))(*[int(x) for x in next(it)])
+                keep.append(flags)
+                cargs.append(ctypes.addressof(flags))
+            elif c == "n":
+                cargs.append(n_table)
+            elif c == "V":
+                vals = np.ascontiguousarray(next(it), dtype=np.float32)
+                keep.append(vals)
+                cargs += [vals.ctypes.data, int(vals.size)]
             elif c == "s":
                 cargs.append(next(it).encode())
             elif c == "f":
@@ -106,7 +173,7 @@ class CpuLib:
             else:
                 cargs.append(int(next(it)))
         fd = ctypes.c_int(int(fdefined))
-        ok = self._fn[name](nx, ny, *cargs, ctypes.addressof(fd), float(undef))
+        ok = self._fn[name](*lead, nx, ny, *cargs, ctypes.addressof(fd), float(undef))
         res = outs[0] if n_out == 1 else tuple(outs)
         return bool(ok), res, fd.value
 

@@ -25,15 +25,24 @@ from cpulib import CpuLib  # noqa: E402
 
 GOLDEN_STENCIL_GRIDS = [(3, 3), (5, 4), (17, 9), (64, 48), (260, 11)]
 GOLDEN_EWISE_GRIDS = [(1, 1), (5, 4), (17, 9)]
+GOLDEN_CATALOGUE_GRIDS = [(5, 4), (17, 9)]
+GOLDEN_ENSEMBLE_GRIDS = [(5, 4), (17, 9)]
 
 
 def input_digest(case):
     h = hashlib.sha256()
-    for a in case["args"]:
+    def feed(a):
         if isinstance(a, np.ndarray):
             h.update(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+        elif isinstance(a, (list, tuple)):  # table of member fields, per-member flags, limits
+            h.update(b"[%d]" % len(a))
+            for x in a:
+                feed(x)
         else:
             h.update(repr(a).encode())
+
+    for a in case["args"]:
+        feed(a)
     h.update(repr((case["nx"], case["ny"], case["fdefined"], float(case["undef"]))).encode())
     return h.hexdigest()
 
@@ -65,6 +74,10 @@ def main():
     np.savez_compressed(os.path.join(HERE, "stencil_golden.npz"), **st)
     ew = build(ref, cases.ewise_cases(grids=GOLDEN_EWISE_GRIDS))
     np.savez_compressed(os.path.join(HERE, "ewise_golden.npz"), **ew)
+    cat = build(ref, cases.catalogue_cases(grids=GOLDEN_CATALOGUE_GRIDS))
+    np.savez_compressed(os.path.join(HERE, "catalogue_golden.npz"), **cat)
+    ens = build(ref, cases.ensemble_cases(grids=GOLDEN_ENSEMBLE_GRIDS))
+    np.savez_compressed(os.path.join(HERE, "ensemble_golden.npz"), **ens)
 
     # headline level, digests only
     import mi_fieldcalc_amd.synth as synth
@@ -82,7 +95,7 @@ def main():
             big["%s-%s/in" % (op, mode)] = np.frombuffer(bytes.fromhex(input_digest(case)), dtype=np.uint8)
             big["%s-%s/out" % (op, mode)] = np.frombuffer(hashlib.sha256(out.tobytes()).digest(), dtype=np.uint8)
     np.savez_compressed(os.path.join(HERE, "headline_level_digests.npz"), **big)
-    for f in ("stencil_golden.npz", "ewise_golden.npz", "headline_level_digests.npz"):
+    for f in ("stencil_golden.npz", "ewise_golden.npz", "catalogue_golden.npz", "ensemble_golden.npz", "headline_level_digests.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -12,15 +12,24 @@ GOLDEN = os.path.join(HERE, "golden")
 
 GOLDEN_STENCIL_GRIDS = [(3, 3), (5, 4), (17, 9), (64, 48), (260, 11)]
 GOLDEN_EWISE_GRIDS = [(1, 1), (5, 4), (17, 9)]
+GOLDEN_CATALOGUE_GRIDS = [(5, 4), (17, 9)]
+GOLDEN_ENSEMBLE_GRIDS = [(5, 4), (17, 9)]
 
 
 def input_digest(case):
     h = hashlib.sha256()
-    for a in case["args"]:
+    def feed(a):
         if isinstance(a, np.ndarray):
             h.update(np.ascontiguousarray(a, dtype=np.float32).tobytes())
+        elif isinstance(a, (list, tuple)):  # table of member fields, per-member flags, limits
+            h.update(b"[%d]" % len(a))
+            for x in a:
+                feed(x)
         else:
             h.update(repr(a).encode())
+
+    for a in case["args"]:
+        feed(a)
     h.update(repr((case["nx"], case["ny"], case["fdefined"], float(case["undef"]))).encode())
     return h.hexdigest()
 
@@ -48,3 +57,13 @@ def stencil_golden_cases():
 def ewise_golden_cases():
     g = Golden("ewise_golden.npz")
     return g, [c for c in cases.ewise_cases(grids=GOLDEN_EWISE_GRIDS) if c["label"] in g.labels]
+
+
+def catalogue_golden_cases():
+    g = Golden("catalogue_golden.npz")
+    return g, [c for c in cases.catalogue_cases(grids=GOLDEN_CATALOGUE_GRIDS) if c["label"] in g.labels]
+
+
+def ensemble_golden_cases():
+    g = Golden("ensemble_golden.npz")
+    return g, [c for c in cases.ensemble_cases(grids=GOLDEN_ENSEMBLE_GRIDS) if c["label"] in g.labels]

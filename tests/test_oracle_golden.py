@@ -41,6 +41,16 @@ def test_oracle_matches_ewise_golden(oracle):
     assert _check_against_golden(oracle, g, cs) > 1000
 
 
+def test_oracle_matches_catalogue_golden(oracle):
+    g, cs = golden_util.catalogue_golden_cases()
+    assert _check_against_golden(oracle, g, cs) > 500
+
+
+def test_oracle_matches_ensemble_golden(oracle):
+    g, cs = golden_util.ensemble_golden_cases()
+    assert _check_against_golden(oracle, g, cs) > 250
+
+
 def test_oracle_matches_headline_level_digests(oracle):
     import mi_fieldcalc_amd.synth as synth
 

@@ -47,6 +47,22 @@ def test_elementwise_bit_exact(oracle, ref):
         _check(oracle, ref, case)
 
 
+def test_catalogue_bit_exact(oracle, ref):
+    """theta-e, ducting, indices, conversions, field algebra."""
+    cs = cases.catalogue_cases()
+    assert len(cs) > 1500
+    for case in cs:
+        _check(oracle, ref, case)
+
+
+def test_ensemble_reductions_bit_exact(oracle, ref):
+    """SURVEY.md 8f-4."""
+    cs = cases.ensemble_cases()
+    assert len(cs) > 400
+    for case in cs:
+        _check(oracle, ref, case)
+
+
 def test_headline_level_bit_exact(oracle, ref):
     """One full 1440x720 level of the headline configuration, all-defined and with undefined cells."""
     import mi_fieldcalc_amd.synth as synth
