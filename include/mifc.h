@@ -73,6 +73,14 @@ void* mifc_device_alloc(mifc_ctx* ctx, size_t bytes);
 int mifc_device_free(mifc_ctx* ctx, void* dptr);
 int mifc_copy_to_device(mifc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int mifc_copy_to_host(mifc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Host-pointer (MIFC_MEM_HOST) callers: declare a host array that is passed to
+ * many calls unchanged -- xmapr, ymapr, fcoriolis of a grid (FieldCalculations.h:
+ * every stencil operator takes them) -- so that it is uploaded once instead of
+ * per call.  The content must not change while held; hold again to refresh,
+ * release before freeing the array.  No counterpart in the reference, whose
+ * operators read the caller's memory directly. */
+int mifc_hold_field(mifc_ctx* ctx, const float* host_field, size_t n_floats);
+int mifc_release_field(mifc_ctx* ctx, const float* host_field);
 /* miutil::checkDefined(size_t,size_t), FieldDefined.cc:62-70 */
 int mifc_classify(unsigned long long n_undefined, unsigned long long n);
 
@@ -136,6 +144,77 @@ int mifc_thermalFrontParameter(mifc_ctx* ctx, int nx, int ny, const float* tx, c
  * compute 1/2 = x component from T / theta, 3/4 = y component) */
 int mifc_plevelqvector(mifc_ctx* ctx, int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr,
                        const float* fcoriolis, float p, int compute, float* qcomp, int* fdefined, float undef, int memkind);
+
+/* ---- the rest of the pointwise catalogue, one field per call ----
+ * Each entry replaces the miutil::fieldcalc function of the same name; the
+ * comment gives FieldCalculations.h:line / FieldCalculations.cc:line.  Argument
+ * order is the reference's (fieldOPER* take `compute` first, like there).  The
+ * reference's void functions return 1 here. */
+/* plevelthe .h:115 / .cc:369; hlevelthe .h:157 / .cc:1100; alevelthe .h:174 / .cc:1355 */
+int mifc_plevelthe(mifc_ctx* ctx, int nx, int ny, const float* t, const float* rh, float p, int compute, float* the, int* fdefined, float undef,
+                   int memkind);
+int mifc_hlevelthe(mifc_ctx* ctx, int nx, int ny, const float* t, const float* q, const float* ps, float alevel, float blevel, int compute,
+                   float* the, int* fdefined, float undef, int memkind);
+int mifc_alevelthe(mifc_ctx* ctx, int nx, int ny, const float* t, const float* q, const float* p, int compute, float* the, int* fdefined, float undef,
+                   int memkind);
+/* plevelducting .h:125 / .cc:597; hlevelducting .h:163 / .cc:1219; alevelducting .h:179 / .cc:1460 */
+int mifc_plevelducting(mifc_ctx* ctx, int nx, int ny, const float* t, const float* h, float p, int compute, float* duct, int* fdefined, float undef,
+                       int memkind);
+int mifc_hlevelducting(mifc_ctx* ctx, int nx, int ny, const float* t, const float* h, const float* ps, float alevel, float blevel, int compute,
+                       float* duct, int* fdefined, float undef, int memkind);
+int mifc_alevelducting(mifc_ctx* ctx, int nx, int ny, const float* t, const float* h, const float* p, int compute, float* duct, int* fdefined,
+                       float undef, int memkind);
+/* hlevelpressure .h:166 / .cc:1276; pleveldz2tmean .h:120 / .cc:466 */
+int mifc_hlevelpressure(mifc_ctx* ctx, int nx, int ny, const float* ps, float alevel, float blevel, float* p, int* fdefined, float undef,
+                        int memkind);
+int mifc_pleveldz2tmean(mifc_ctx* ctx, int nx, int ny, const float* z1, const float* z2, float p1, float p2, int compute, float* tmean,
+                        int* fdefined, float undef, int memkind);
+/* kIndex .h:136 / .cc:745; ductingIndex .h:139 / .cc:816; showalterIndex .h:141 / .cc:872; boydenIndex .h:144 / .cc:973; sweatIndex .h:147 / .cc:1016 */
+int mifc_kIndex(mifc_ctx* ctx, int nx, int ny, const float* t500, const float* t700, const float* rh700, const float* t850, const float* rh850,
+                float p500, float p700, float p850, int compute, float* kfield, int* fdefined, float undef, int memkind);
+int mifc_ductingIndex(mifc_ctx* ctx, int nx, int ny, const float* t850, const float* rh850, float p850, int compute, float* duct, int* fdefined,
+                      float undef, int memkind);
+int mifc_showalterIndex(mifc_ctx* ctx, int nx, int ny, const float* t500, const float* t850, const float* rh850, float p500, float p850, int compute,
+                        float* sfield, int* fdefined, float undef, int memkind);
+int mifc_boydenIndex(mifc_ctx* ctx, int nx, int ny, const float* t700, const float* z700, const float* z1000, float p700, float p1000, int compute,
+                     float* bfield, int* fdefined, float undef, int memkind);
+int mifc_sweatIndex(mifc_ctx* ctx, int nx, int ny, const float* t850, const float* t500, const float* td850, const float* td500, const float* u850,
+                    const float* v850, const float* u500, const float* v500, float* sindex, int* fdefined, float undef, int memkind);
+/* seaSoundSpeed .h:192 / .cc:1555; cvtemp .h:198 / .cc:1608; abshum .h:202 / .cc:1676; windCooling .h:220 / .cc:2181;
+ * underCooledRain .h:222 / .cc:2231; pressure2FlightLevel .h:227 / .cc:2311; snow_in_cm .h:303 / .cc:3063 */
+int mifc_seaSoundSpeed(mifc_ctx* ctx, int nx, int ny, const float* t, const float* s, float z, int compute, float* soundspeed, int* fdefined,
+                       float undef, int memkind);
+int mifc_cvtemp(mifc_ctx* ctx, int nx, int ny, const float* tinp, int compute, float* tout, int* fdefined, float undef, int memkind);
+int mifc_abshum(mifc_ctx* ctx, int nx, int ny, const float* t, const float* rhum, float* abshumout, int* fdefined, float undef, int memkind);
+int mifc_windCooling(mifc_ctx* ctx, int nx, int ny, const float* t, const float* u, const float* v, int compute, float* dtcool, int* fdefined,
+                     float undef, int memkind);
+int mifc_underCooledRain(mifc_ctx* ctx, int nx, int ny, const float* precip, const float* snow, const float* tk, float precipMin, float snowRateMax,
+                         float tcMax, float* undercooled, int* fdefined, float undef, int memkind);
+int mifc_pressure2FlightLevel(mifc_ctx* ctx, int nx, int ny, const float* pressure, float* flightlevel, int* fdefined, float undef, int memkind);
+int mifc_snow_in_cm(mifc_ctx* ctx, int nx, int ny, const float* snow_water, const float* tk2m, const float* td2m, float* snow_cm, int* fdefined,
+                    float undef, int memkind);
+/* values2classes .h:252 / .cc:2462: `values` (class limits, std::vector<float> there) is always a HOST array */
+int mifc_values2classes(mifc_ctx* ctx, int nx, int ny, const float* fvalue, float* fclass, const float* values, int nvalues, int* fdefined,
+                        float undef, int memkind);
+/* field algebra .h:254-282 / .cc:2501-2669 */
+int mifc_minvalueFields(mifc_ctx* ctx, int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef, int memkind);
+int mifc_maxvalueFields(mifc_ctx* ctx, int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef, int memkind);
+int mifc_minvalueFieldConst(mifc_ctx* ctx, int nx, int ny, const float* field1, float value, float* fres, int* fdefined, float undef, int memkind);
+int mifc_maxvalueFieldConst(mifc_ctx* ctx, int nx, int ny, const float* field1, float value, float* fres, int* fdefined, float undef, int memkind);
+int mifc_absvalueField(mifc_ctx* ctx, int nx, int ny, const float* field, float* fres, int* fdefined, float undef, int memkind);
+int mifc_log10Field(mifc_ctx* ctx, int nx, int ny, const float* field, float* fres, int* fdefined, float undef, int memkind);
+int mifc_pow10Field(mifc_ctx* ctx, int nx, int ny, const float* field, float* fres, int* fdefined, float undef, int memkind);
+int mifc_logField(mifc_ctx* ctx, int nx, int ny, const float* field, float* fres, int* fdefined, float undef, int memkind);
+int mifc_expField(mifc_ctx* ctx, int nx, int ny, const float* field, float* fres, int* fdefined, float undef, int memkind);
+int mifc_powerField(mifc_ctx* ctx, int nx, int ny, const float* field, float value, float* fres, int* fdefined, float undef, int memkind);
+int mifc_replaceUndefined(mifc_ctx* ctx, int nx, int ny, const float* field, float value, float* fres, int* fdefined, float undef, int memkind);
+int mifc_replaceDefined(mifc_ctx* ctx, int nx, int ny, const float* field, float value, float* fres, int* fdefined, float undef, int memkind);
+int mifc_fieldOPERfield(mifc_ctx* ctx, int compute, int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef,
+                        int memkind);
+int mifc_fieldOPERconstant(mifc_ctx* ctx, int compute, int nx, int ny, const float* field, float value, float* fres, int* fdefined, float undef,
+                           int memkind);
+int mifc_constantOPERfield(mifc_ctx* ctx, int compute, int nx, int ny, float value, const float* field, float* fres, int* fdefined, float undef,
+                           int memkind);
 
 /* ---- batched over vertical levels / ensemble members (new surface) ------ */
 /* The reference is called once per 2-D field; a caller that wants vorticity

@@ -127,6 +127,26 @@ class Context:
         if not self._lib.mifc_synchronize(self._ctx):
             raise RuntimeError(self.last_error())
 
+    def hold_field(self, host_array):
+        """Uploads a constant host field (map ratios, Coriolis parameter) once;
+        host-pointer calls that are handed the same array then skip its upload.
+        The array must stay alive and unchanged until release_field()."""
+        a = _Arg(host_array)
+        if a.device:
+            raise ValueError("hold_field is for host arrays")
+        if a.keep is not host_array:
+            raise ValueError("hold_field needs a C-contiguous float32 array (a converted copy would have another address)")
+        self._held = getattr(self, "_held", {})
+        self._held[a.addr] = a.keep
+        if not self._lib.mifc_hold_field(self._ctx, a.addr, int(a.keep.size)):
+            raise RuntimeError(self.last_error())
+        return a.keep
+
+    def release_field(self, host_array):
+        a = _Arg(host_array)
+        self._lib.mifc_release_field(self._ctx, a.addr)
+        getattr(self, "_held", {}).pop(a.addr, None)
+
     # ------------------------------------------------------------ call helper
     def _bind_stream(self, memkind):
         """Fields resident on the device come from PyTorch: run on torch's
@@ -150,9 +170,11 @@ class Context:
         ny, nx = a.shape[-2], a.shape[-1]
         return nx, ny
 
-    def _single(self, name, fields, scalars, outs, fdefined, undef, n_out=1, out_like=None):
+    def _single(self, name, fields, scalars, outs, fdefined, undef, n_out=1, out_like=None, lead=(), pre=(), tail=()):
         """fields: input arrays (None allowed), scalars: list placed between
-        inputs and outputs in reference order, outs: preallocated or None."""
+        inputs and outputs in reference order, outs: preallocated or None.
+        lead: arguments before (nx, ny) (fieldOPER*'s compute), pre: scalars
+        before the fields, tail: arguments between the outputs and the flag."""
         fa = [_Arg(f, allow_none=True) for f in fields]
         ref = next(f for f in fields if f is not None)
         nx, ny = self._nxny(_Arg(ref))
@@ -164,7 +186,8 @@ class Context:
         mk = _memkind(fa + oa)
         self._bind_stream(mk)
         fd = ctypes.c_int(int(fdefined))
-        args = [nx, ny] + [a.addr for a in fa] + list(scalars) + [a.addr for a in oa] + [ctypes.addressof(fd), float(undef), mk]
+        args = (list(lead) + [nx, ny] + list(pre) + [a.addr for a in fa] + list(scalars) + [a.addr for a in oa] + list(tail)
+                + [ctypes.addressof(fd), float(undef), mk])
         if not self._call(name, args):
             return None
         res = [o if _is_torch(o) else a.keep for o, a in zip(outs, oa)]
@@ -243,6 +266,119 @@ class Context:
 
     def plevelqvector(self, z, t, xmapr, ymapr, fcoriolis, p, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
         return self._single("mifc_plevelqvector", [z, t, xmapr, ymapr, fcoriolis], [float(p), int(compute)], [out], fdefined, undef)
+
+    # ---------------------------- the rest of the pointwise catalogue
+    # Same argument order as miutil::fieldcalc; (result, flag) or None like the others.
+    def plevelthe(self, t, rh, p, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_plevelthe", [t, rh], [float(p), int(compute)], [out], fdefined, undef)
+
+    def hlevelthe(self, t, q, ps, alevel, blevel, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_hlevelthe", [t, q, ps], [float(alevel), float(blevel), int(compute)], [out], fdefined, undef)
+
+    def alevelthe(self, t, q, p, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_alevelthe", [t, q, p], [int(compute)], [out], fdefined, undef)
+
+    def plevelducting(self, t, h, p, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_plevelducting", [t, h], [float(p), int(compute)], [out], fdefined, undef)
+
+    def hlevelducting(self, t, h, ps, alevel, blevel, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_hlevelducting", [t, h, ps], [float(alevel), float(blevel), int(compute)], [out], fdefined, undef)
+
+    def alevelducting(self, t, h, p, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_alevelducting", [t, h, p], [int(compute)], [out], fdefined, undef)
+
+    def hlevelpressure(self, ps, alevel, blevel, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_hlevelpressure", [ps], [float(alevel), float(blevel)], [out], fdefined, undef)
+
+    def pleveldz2tmean(self, z1, z2, p1, p2, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_pleveldz2tmean", [z1, z2], [float(p1), float(p2), int(compute)], [out], fdefined, undef)
+
+    def kIndex(self, t500, t700, rh700, t850, rh850, p500, p700, p850, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_kIndex", [t500, t700, rh700, t850, rh850], [float(p500), float(p700), float(p850), int(compute)], [out],
+                            fdefined, undef)
+
+    def ductingIndex(self, t850, rh850, p850, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_ductingIndex", [t850, rh850], [float(p850), int(compute)], [out], fdefined, undef)
+
+    def showalterIndex(self, t500, t850, rh850, p500, p850, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_showalterIndex", [t500, t850, rh850], [float(p500), float(p850), int(compute)], [out], fdefined, undef)
+
+    def boydenIndex(self, t700, z700, z1000, p700, p1000, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_boydenIndex", [t700, z700, z1000], [float(p700), float(p1000), int(compute)], [out], fdefined, undef)
+
+    def sweatIndex(self, t850, t500, td850, td500, u850, v850, u500, v500, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_sweatIndex", [t850, t500, td850, td500, u850, v850, u500, v500], [], [out], fdefined, undef)
+
+    def seaSoundSpeed(self, t, s, z, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_seaSoundSpeed", [t, s], [float(z), int(compute)], [out], fdefined, undef)
+
+    def cvtemp(self, tinp, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_cvtemp", [tinp], [int(compute)], [out], fdefined, undef)
+
+    def abshum(self, t, rhum, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_abshum", [t, rhum], [], [out], fdefined, undef)
+
+    def windCooling(self, t, u, v, compute, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_windCooling", [t, u, v], [int(compute)], [out], fdefined, undef)
+
+    def underCooledRain(self, precip, snow, tk, precipMin, snowRateMax, tcMax, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_underCooledRain", [precip, snow, tk], [float(precipMin), float(snowRateMax), float(tcMax)], [out], fdefined, undef)
+
+    def pressure2FlightLevel(self, pressure, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_pressure2FlightLevel", [pressure], [], [out], fdefined, undef)
+
+    def snow_in_cm(self, snow_water, tk2m, td2m, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_snow_in_cm", [snow_water, tk2m, td2m], [], [out], fdefined, undef)
+
+    def values2classes(self, fvalue, values, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        """values: the class limits (host sequence).  C order: fvalue, fclass (output), values, nvalues."""
+        vals = np.ascontiguousarray(values, dtype=np.float32)
+        return self._single("mifc_values2classes", [fvalue], [], [out], fdefined, undef, tail=[vals.ctypes.data, int(vals.size)])
+
+    def minvalueFields(self, field1, field2, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_minvalueFields", [field1, field2], [], [out], fdefined, undef)
+
+    def maxvalueFields(self, field1, field2, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_maxvalueFields", [field1, field2], [], [out], fdefined, undef)
+
+    def minvalueFieldConst(self, field1, value, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_minvalueFieldConst", [field1], [float(value)], [out], fdefined, undef)
+
+    def maxvalueFieldConst(self, field1, value, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_maxvalueFieldConst", [field1], [float(value)], [out], fdefined, undef)
+
+    def absvalueField(self, field, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_absvalueField", [field], [], [out], fdefined, undef)
+
+    def log10Field(self, field, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_log10Field", [field], [], [out], fdefined, undef)
+
+    def pow10Field(self, field, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_pow10Field", [field], [], [out], fdefined, undef)
+
+    def logField(self, field, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_logField", [field], [], [out], fdefined, undef)
+
+    def expField(self, field, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_expField", [field], [], [out], fdefined, undef)
+
+    def powerField(self, field, value, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_powerField", [field], [float(value)], [out], fdefined, undef)
+
+    def replaceUndefined(self, field, value, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_replaceUndefined", [field], [float(value)], [out], fdefined, undef)
+
+    def replaceDefined(self, field, value, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_replaceDefined", [field], [float(value)], [out], fdefined, undef)
+
+    def fieldOPERfield(self, compute, field1, field2, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_fieldOPERfield", [field1, field2], [], [out], fdefined, undef, lead=[int(compute)])
+
+    def fieldOPERconstant(self, compute, field, value, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_fieldOPERconstant", [field], [float(value)], [out], fdefined, undef, lead=[int(compute)])
+
+    def constantOPERfield(self, compute, value, field, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_constantOPERfield", [field], [], [out], fdefined, undef, lead=[int(compute)], pre=[float(value)])
 
     # ------------------------------------------------------------------ batched
     def vortdiv_levels(self, u, v, xmapr, ymapr, fdefined=None, undef=UNDEF, rvort=None, diverg=None, want=("rvort", "diverg")):

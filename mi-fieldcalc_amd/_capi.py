@@ -40,6 +40,8 @@ SIGNATURES = {
     "mifc_device_free": ("i", ["ctx", "p"]),
     "mifc_copy_to_device": ("i", ["ctx", "p", "p", "z"]),
     "mifc_copy_to_host": ("i", ["ctx", "p", "p", "z"]),
+    "mifc_hold_field": ("i", ["ctx", "p", "z"]),
+    "mifc_release_field": ("i", ["ctx", "p"]),
     "mifc_classify": ("i", ["u64", "u64"]),
     # elementwise
     "mifc_vectorabs": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
@@ -66,6 +68,43 @@ SIGNATURES = {
     "mifc_momentumYcoordinate": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "p", "pi", "f", "i"]),
     "mifc_thermalFrontParameter": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_plevelqvector": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "f", "i", "p", "pi", "f", "i"]),
+    # the rest of the pointwise catalogue
+    "mifc_plevelthe": ("i", ["ctx", "i", "i", "p", "p", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_hlevelthe": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_alevelthe": ("i", ["ctx", "i", "i", "p", "p", "p", "i", "p", "pi", "f", "i"]),
+    "mifc_plevelducting": ("i", ["ctx", "i", "i", "p", "p", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_hlevelducting": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_alevelducting": ("i", ["ctx", "i", "i", "p", "p", "p", "i", "p", "pi", "f", "i"]),
+    "mifc_hlevelpressure": ("i", ["ctx", "i", "i", "p", "f", "f", "p", "pi", "f", "i"]),
+    "mifc_pleveldz2tmean": ("i", ["ctx", "i", "i", "p", "p", "f", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_kIndex": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "f", "f", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_ductingIndex": ("i", ["ctx", "i", "i", "p", "p", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_showalterIndex": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_boydenIndex": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_sweatIndex": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_seaSoundSpeed": ("i", ["ctx", "i", "i", "p", "p", "f", "i", "p", "pi", "f", "i"]),
+    "mifc_cvtemp": ("i", ["ctx", "i", "i", "p", "i", "p", "pi", "f", "i"]),
+    "mifc_abshum": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_windCooling": ("i", ["ctx", "i", "i", "p", "p", "p", "i", "p", "pi", "f", "i"]),
+    "mifc_underCooledRain": ("i", ["ctx", "i", "i", "p", "p", "p", "f", "f", "f", "p", "pi", "f", "i"]),
+    "mifc_pressure2FlightLevel": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
+    "mifc_snow_in_cm": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_values2classes": ("i", ["ctx", "i", "i", "p", "p", "p", "i", "pi", "f", "i"]),
+    "mifc_minvalueFields": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_maxvalueFields": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_minvalueFieldConst": ("i", ["ctx", "i", "i", "p", "f", "p", "pi", "f", "i"]),
+    "mifc_maxvalueFieldConst": ("i", ["ctx", "i", "i", "p", "f", "p", "pi", "f", "i"]),
+    "mifc_absvalueField": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
+    "mifc_log10Field": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
+    "mifc_pow10Field": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
+    "mifc_logField": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
+    "mifc_expField": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
+    "mifc_powerField": ("i", ["ctx", "i", "i", "p", "f", "p", "pi", "f", "i"]),
+    "mifc_replaceUndefined": ("i", ["ctx", "i", "i", "p", "f", "p", "pi", "f", "i"]),
+    "mifc_replaceDefined": ("i", ["ctx", "i", "i", "p", "f", "p", "pi", "f", "i"]),
+    "mifc_fieldOPERfield": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_fieldOPERconstant": ("i", ["ctx", "i", "i", "i", "p", "f", "p", "pi", "f", "i"]),
+    "mifc_constantOPERfield": ("i", ["ctx", "i", "i", "i", "f", "p", "p", "pi", "f", "i"]),
     # batched
     "mifc_vortdiv_levels": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_stencil_levels": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),

@@ -5,43 +5,19 @@
 // legacy host pointers through device scratch, launching the HIP kernels and
 // turning the per-field undefined counts into ValuesDefined flags.  There is
 // no CPU compute path: every operator body runs on the GPU.
-#include "../../include/mifc.h"
-#include "mifc_kernels.h"
-
-#include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
-using mifc::u64;
+#include "mifc_ctx.h"
 
-struct mifc_ctx
-{
-  int device = 0;
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
-  std::string err;
-  // grow-only device scratch slots for staged host fields
-  static const int NSLOT = 10;
-  void* slot[NSLOT] = {nullptr};
-  size_t slot_bytes[NSLOT] = {0};
-  // per-level flags / counters
-  unsigned char* d_flags = nullptr; // 2 * cap_lev bytes (wind | thermo, or just one set)
-  u64* d_counts = nullptr;          // 3 * cap_lev
-  float* d_ab = nullptr;            // 2 * cap_lev (alevel | blevel)
-  void* h_pinned = nullptr;         // pinned mirror: counts (3*cap u64) + flags (2*cap) + ab (2*cap float)
-  size_t cap_lev = 0;
-  // recorded after every async copy that READS the pinned mirror (enqueue
-  // variants); waited on before the mirror is rewritten
-  hipEvent_t pinned_read = nullptr;
-  bool pinned_read_pending = false;
-};
+namespace mifc_host {
 
-namespace {
 
 bool fail(mifc_ctx* c, const char* what, hipError_t e)
 {
@@ -52,14 +28,6 @@ bool fail(mifc_ctx* c, const char* what, hipError_t e)
   return false;
 }
 
-#define MIFC_HIP(c, call)                    \
-  do {                                       \
-    hipError_t e_ = (call);                  \
-    if (e_ != hipSuccess) {                  \
-      fail((c), #call, e_);                  \
-      return 0;                              \
-    }                                        \
-  } while (0)
 
 bool ensure_slot(mifc_ctx* c, int s, size_t bytes)
 {
@@ -154,6 +122,9 @@ const float* stage_in(mifc_ctx* c, int s, const float* p, size_t n, int memkind,
 {
   if (!p || memkind == MIFC_MEM_DEVICE)
     return p;
+  for (const mifc_ctx::HeldField& h : c->held)
+    if (h.host == p && h.n >= n)
+      return h.dev; // declared constant by the caller: already resident
   if (!ensure_slot(c, s, n * sizeof(float))) {
     *ok = false;
     return nullptr;
@@ -167,7 +138,7 @@ const float* stage_in(mifc_ctx* c, int s, const float* p, size_t n, int memkind,
   return static_cast<const float*>(c->slot[s]);
 }
 
-float* stage_out(mifc_ctx* c, int s, float* p, size_t n, int memkind, bool* ok, bool preload = false)
+float* stage_out(mifc_ctx* c, int s, float* p, size_t n, int memkind, bool* ok, bool preload)
 {
   if (!p || memkind == MIFC_MEM_DEVICE)
     return p;
@@ -201,15 +172,11 @@ inline bool unit_is(const char* unit, const char* what)
   return unit && std::strcmp(unit, what) == 0;
 }
 
-// MetConstants.h:43-53 (host copies, evaluated like the reference does on the CPU)
-const float K_CP = 1004.f, K_T0 = 273.15f;
-const float K_P0INV = (float)(1. / 1000.0);
-const float K_KAPPA = 287.f / 1004.f;
+} // namespace mifc_host
 
-inline bool bad_hlevel(float a, float b) // FieldCalculations.cc:298-301
-{
-  return (a < 0.0) || (b < 0.0) || (a == 0.0 && b == 0.0) || (b > 1.0);
-}
+using namespace mifc_host;
+
+namespace {
 
 // ---- single-field elementwise driver --------------------------------------
 int run_ewise(mifc_ctx* c, mifc::EwiseParams P, const float* in0, const float* in1, const float* in2, float* out, int* fdefined, int memkind,
@@ -271,6 +238,12 @@ u64 stencil_denominator(int op, int nx, int ny)
   return n - 2 * (u64)nx; // :1868 and friends, also gradient compute 1 (:2068)
 }
 
+bool host_pipeline_enabled()
+{
+  const char* e = std::getenv("MIFC_HOST_PIPELINE"); // "0": stage whole batches (for A/B measurements)
+  return !(e && e[0] == '0');
+}
+
 int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, float undef, int memkind)
 {
   if (sc.nx < 3 || sc.ny < 3 || sc.nlev < 1)
@@ -286,14 +259,29 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
   P.j0 = 0;
   P.ny_local = sc.ny;
   P.nlev = sc.nlev;
-  P.f0 = stage_in(c, 0, sc.f0, nb, memkind, &ok);
-  P.f1 = stage_in(c, 1, sc.f1, nb, memkind, &ok);
+  // A large level batch in host memory is streamed through the device in
+  // chunks, copies in both directions overlapping the kernels (mifc_hostpipe.h);
+  // everything else is staged whole.
+  const bool piped = memkind == MIFC_MEM_HOST && !sc.f2 && sc.f0 && (sc.o0 || sc.o1) && mifc::hostpipe_chunk_levels(n, sc.nlev) > 0 && host_pipeline_enabled();
+  if (piped) {
+    if (!c->pipe && !(c->pipe = mifc::hostpipe_create(c->device))) {
+      c->err = "host pipeline: cannot create streams";
+      return 0;
+    }
+    P.f0 = sc.f0; // placeholders (non-null where the operator has the field); the chunk launcher substitutes device buffers
+    P.f1 = sc.f1;
+    P.out0 = sc.o0;
+    P.out1 = sc.o1;
+  } else {
+    P.f0 = stage_in(c, 0, sc.f0, nb, memkind, &ok);
+    P.f1 = stage_in(c, 1, sc.f1, nb, memkind, &ok);
+    P.out0 = stage_out(c, 5, sc.o0, nb, memkind, &ok);
+    P.out1 = stage_out(c, 6, sc.o1, nb, memkind, &ok);
+    P.f2 = stage_in(c, 7, sc.f2, nb, memkind, &ok);
+  }
   P.xmapr = stage_in(c, 2, sc.xm, n, memkind, &ok);
   P.ymapr = stage_in(c, 3, sc.ym, n, memkind, &ok);
   P.fcoriolis = stage_in(c, 4, sc.fc, n, memkind, &ok);
-  P.out0 = stage_out(c, 5, sc.o0, nb, memkind, &ok);
-  P.out1 = stage_out(c, 6, sc.o1, nb, memkind, &ok);
-  P.f2 = stage_in(c, 7, sc.f2, nb, memkind, &ok);
   P.scale = sc.scale;
   P.scale2 = sc.scale2;
   if (!ok || !ensure_levels(c, (size_t)sc.nlev))
@@ -329,11 +317,35 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
     MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)sc.nlev, hipMemcpyHostToDevice, c->stream));
     MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64) * (size_t)sc.nlev, c->stream));
   }
-  MIFC_HIP(c, mifc::launch_stencil(P, c->stream));
-  if (!every_all)
-    MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64) * (size_t)sc.nlev, hipMemcpyDeviceToHost, c->stream));
-  if (!fetch_out(c, 5, sc.o0, nb, memkind) || !fetch_out(c, 6, sc.o1, nb, memkind))
-    return 0;
+  if (piped) {
+    MIFC_HIP(c, hipStreamSynchronize(c->stream)); // maps, flags and zeroed counters are in place
+    // P.out0 / P.out1 may have been swapped above (only one of the two wanted)
+    const float* h_in[2] = {sc.f0, sc.f1};
+    float* h_out[2] = {P.out0, P.out1};
+    const int n_in = sc.f1 ? 2 : 1;
+    const mifc::StencilParams base = P;
+    const mifc::ChunkLaunch launch = [&base](int l0, int nl, const float* const* d_in, float* const* d_out, hipStream_t stream) {
+      mifc::StencilParams q = base;
+      q.nlev = nl;
+      q.f0 = d_in[0];
+      q.f1 = base.f1 ? d_in[1] : nullptr;
+      q.out0 = d_out[0];
+      q.out1 = d_out[1];
+      q.all_defined = base.all_defined + l0;
+      q.n_undefined = base.n_undefined + l0;
+      return mifc::launch_stencil(q, stream);
+    };
+    if (!mifc::hostpipe_run(c->pipe, n, sc.nlev, n_in, h_in, 2, h_out, launch, &c->err))
+      return 0;
+    if (!every_all)
+      MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64) * (size_t)sc.nlev, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    MIFC_HIP(c, mifc::launch_stencil(P, c->stream));
+    if (!every_all)
+      MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64) * (size_t)sc.nlev, hipMemcpyDeviceToHost, c->stream));
+    if (!fetch_out(c, 5, sc.o0, nb, memkind) || !fetch_out(c, 6, sc.o1, nb, memkind))
+      return 0;
+  }
   MIFC_HIP(c, hipStreamSynchronize(c->stream));
   const u64 denom = stencil_denominator(sc.op, sc.nx, sc.ny);
   for (int l = 0; l < sc.nlev; ++l) {
@@ -405,6 +417,9 @@ void mifc_destroy(mifc_ctx* c)
     (void)hipHostFree(c->h_pinned);
   if (c->pinned_read)
     (void)hipEventDestroy(c->pinned_read);
+  mifc::hostpipe_destroy(c->pipe);
+  for (const mifc_ctx::HeldField& h : c->held)
+    (void)hipFree(h.dev);
   if (c->own_stream)
     (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -481,6 +496,61 @@ int mifc_copy_to_host(mifc_ctx* c, void* dst_host, const void* src_dev, size_t b
   MIFC_HIP(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
   MIFC_HIP(c, hipStreamSynchronize(c->stream));
   return 1;
+}
+
+// Constant host fields (map ratios, Coriolis parameter): a caller that passes
+// the same host array to many calls declares it once; host-pointer calls then
+// find the device copy instead of uploading it again.  The caller promises not
+// to change the content while it is held (there is no cheap way to notice: a
+// checksum of the field costs more host time than the upload it would save).
+int mifc_hold_field(mifc_ctx* c, const float* host_field, size_t n_floats)
+{
+  if (!c || !host_field || n_floats == 0)
+    return 0;
+  c->err.clear();
+  for (mifc_ctx::HeldField& h : c->held) {
+    if (h.host == host_field) { // refresh (content or size may have changed)
+      if (h.n < n_floats) {
+        MIFC_HIP(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(h.dev);
+        h.dev = nullptr;
+        h.n = 0;
+        MIFC_HIP(c, hipMalloc((void**)&h.dev, n_floats * sizeof(float)));
+        h.n = n_floats;
+      }
+      MIFC_HIP(c, hipMemcpyAsync(h.dev, host_field, n_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+      return 1;
+    }
+  }
+  mifc_ctx::HeldField h = {host_field, n_floats, nullptr};
+  MIFC_HIP(c, hipMalloc((void**)&h.dev, n_floats * sizeof(float)));
+  hipError_t e = hipMemcpyAsync(h.dev, host_field, n_floats * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    (void)hipFree(h.dev);
+    fail(c, "mifc_hold_field", e);
+    return 0;
+  }
+  c->held.push_back(h);
+  return 1;
+}
+
+int mifc_release_field(mifc_ctx* c, const float* host_field)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  for (size_t k = 0; k < c->held.size(); ++k) {
+    if (c->held[k].host == host_field) {
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(c->held[k].dev);
+      c->held.erase(c->held.begin() + (long)k);
+      return 1;
+    }
+  }
+  return 0;
 }
 
 int mifc_classify(unsigned long long n_undefined, unsigned long long n)

@@ -1,0 +1,87 @@
+// mifc_ctx.h -- internals shared by the host-side translation units of the C
+// ABI (mifc_capi.hip: hot path and stencil family; mifc_capi_catalogue.hip: the
+// rest of the pointwise catalogue and the ensemble reductions).  Not installed.
+#ifndef MIFC_CTX_H
+#define MIFC_CTX_H
+
+#include "../../include/mifc.h"
+#include "mifc_hostpipe.h"
+#include "mifc_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+using mifc::u64;
+
+struct mifc_ctx
+{
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // grow-only device scratch slots for staged host fields
+  static const int NSLOT = 10;
+  void* slot[NSLOT] = {nullptr};
+  size_t slot_bytes[NSLOT] = {0};
+  // per-level flags / counters
+  unsigned char* d_flags = nullptr; // 2 * cap_lev bytes (wind | thermo, or just one set)
+  u64* d_counts = nullptr;          // 3 * cap_lev
+  float* d_ab = nullptr;            // 2 * cap_lev (alevel | blevel)
+  void* h_pinned = nullptr;         // pinned mirror: counts (3*cap u64) + flags (2*cap) + ab (2*cap float)
+  size_t cap_lev = 0;
+  // recorded after every async copy that READS the pinned mirror (enqueue
+  // variants); waited on before the mirror is rewritten
+  hipEvent_t pinned_read = nullptr;
+  bool pinned_read_pending = false;
+  // chunked, full-duplex streaming of host-resident level batches (created on first use)
+  mifc::HostPipe* pipe = nullptr;
+  // host fields the caller declared constant (mifc_hold_field): device copies that stage_in reuses
+  struct HeldField
+  {
+    const float* host;
+    size_t n;
+    float* dev;
+  };
+  std::vector<HeldField> held;
+};
+
+namespace mifc_host {
+
+bool fail(mifc_ctx* c, const char* what, hipError_t e);
+
+#define MIFC_HIP(c, call)                    \
+  do {                                       \
+    hipError_t e_ = (call);                  \
+    if (e_ != hipSuccess) {                  \
+      mifc_host::fail((c), #call, e_);       \
+      return 0;                              \
+    }                                        \
+  } while (0)
+
+bool ensure_slot(mifc_ctx* c, int s, size_t bytes);
+bool ensure_levels(mifc_ctx* c, size_t nlev);
+bool pinned_acquire(mifc_ctx* c);
+bool pinned_release(mifc_ctx* c);
+u64* pinned_counts(mifc_ctx* c);
+unsigned char* pinned_flags(mifc_ctx* c);
+float* pinned_ab(mifc_ctx* c);
+// Brings a field to the device if the caller handed a host pointer (slot s of the context's scratch).
+const float* stage_in(mifc_ctx* c, int s, const float* p, size_t n, int memkind, bool* ok);
+float* stage_out(mifc_ctx* c, int s, float* p, size_t n, int memkind, bool* ok, bool preload = false);
+bool fetch_out(mifc_ctx* c, int s, float* p, size_t n, int memkind);
+
+// MetConstants.h:43-53 (host copies, evaluated like the reference does on the CPU)
+const float K_CP = 1004.f, K_T0 = 273.15f;
+const float K_P0INV = (float)(1. / 1000.0);
+const float K_KAPPA = 287.f / 1004.f;
+
+inline bool bad_hlevel(float a, float b) // FieldCalculations.cc:298-301
+{
+  return (a < 0.0) || (b < 0.0) || (a == 0.0 && b == 0.0) || (b > 1.0);
+}
+
+} // namespace mifc_host
+
+#endif // MIFC_CTX_H

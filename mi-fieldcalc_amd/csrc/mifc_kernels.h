@@ -76,6 +76,62 @@ struct DerivedParams
 };
 hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream);
 
+// ------------------------------------------- the rest of the pointwise catalogue
+// (FieldCalculations.cc line of each operator in the comment)
+enum PwOp {
+  PW_PLEVELTHE = 0,   // plevelthe :369: in = t, rh
+  PW_XLEVELTHE,       // hlevelthe :1100 (hybrid) / alevelthe :1355: in = t, q, ps|p
+  PW_PDUCT,           // plevelducting :597: in = t, h
+  PW_XDUCT,           // hlevelducting :1219 (hybrid) / alevelducting :1460: in = t, h, ps|p
+  PW_HPRESSURE,       // hlevelpressure :1276
+  PW_DZ2TMEAN,        // pleveldz2tmean :466
+  PW_KINDEX,          // :745
+  PW_DUCTINDEX,       // :816
+  PW_SHOWALTER,       // :872
+  PW_BOYDEN,          // :973
+  PW_SWEAT,           // :1016
+  PW_SOUNDSPEED,      // seaSoundSpeed :1555
+  PW_ADDCONST,        // cvtemp :1608 (the conversion pass)
+  PW_ABSHUM,          // :1676
+  PW_WINDCOOLING,     // :2181
+  PW_UNDERCOOLED,     // underCooledRain :2231
+  PW_FLIGHTLEVEL,     // pressure2FlightLevel :2311
+  PW_SNOWCM,          // snow_in_cm :3063
+  PW_CLASSES,         // values2classes :2462
+  PW_MINMAX_FIELDS,   // minvalueFields :2501 (compute 1), maxvalueFields :2516 (2)
+  PW_MINMAX_CONST,    // minvalueFieldConst :2507 (1), maxvalueFieldConst :2522 (2)
+  PW_MATH,            // abs 1, log10 2, pow10 3, log 4, exp 5, power 6 (:2531-2563)
+  PW_REPLACE,         // replaceUndefined :2565 (1), replaceDefined :2587 (2), copy (3)
+  PW_FILL,            // fillUndef :76 and the std::fill branches of replace*
+  PW_FIELD_OP_FIELD,  // fieldOPERfield :2611
+  PW_FIELD_OP_CONST,  // fieldOPERconstant :2627
+  PW_CONST_OP_FIELD   // constantOPERfield :2647
+};
+
+struct PwParams
+{
+  int op;
+  int n;
+  int all_defined;          // input flag == ALL_DEFINED
+  int count;                // operator classifies its output (the "Undef" helper templates :142-179 and the hand-written loops)
+  int compute;
+  int hybrid;               // p = s[0] + s[1] * ps (h-level) instead of the p field (a-level)
+  int may_keep;             // some cells may stay unwritten: the kernel starts from the output's content
+  int no_input_test;        // replace*: no is_defined test on the input
+  int skip_undefined_input; // showalterIndex: an undefined input is counted but the cell is not written
+  float undef;
+  float s[8];  // operator scalars, evaluated on the host like the reference does
+  double d[2];
+  const float* in[8];
+  float* out;
+  u64* n_undefined;
+  const float* values; // values2classes: device copy of the class limits
+  int nvalues;
+};
+hipError_t launch_pointwise(const PwParams& prm, hipStream_t stream);
+// sum and number of the defined cells (cvtemp compute 3, 4)
+hipError_t launch_mean_defined(const float* f, int n, int all_defined, float undef, double* sum, unsigned long long* count, hipStream_t stream);
+
 // -------------------------------------------------------------------- stencils
 enum StencilOp {
   ST_RELVORT = 0,    // :1843

@@ -114,11 +114,63 @@ bool thermalFrontParameter(int nx, int ny, const float* t, const float* xmapr, c
 bool plevelqvector(int nx, int ny, const float* z, const float* t, const float* xmapr, const float* ymapr, const float* fcoriolis,
                    float p, int compute, float* qcomp, ValuesDefined& fDefined, float undef);
 
+// ---- the rest of the pointwise catalogue -----------------------------------------
+bool plevelthe(int nx, int ny, const float* t, const float* rh, float p, int compute, float* the, ValuesDefined& fDefined, float undef);
+bool hlevelthe(int nx, int ny, const float* t, const float* q, const float* ps, float alevel, float blevel, int compute,
+               float* the, ValuesDefined& fDefined, float undef);
+bool alevelthe(int nx, int ny, const float* t, const float* q, const float* p, int compute, float* the, ValuesDefined& fDefined, float undef);
+bool plevelducting(int nx, int ny, const float* t, const float* h, float p, int compute, float* duct, ValuesDefined& fDefined, float undef);
+bool hlevelducting(int nx, int ny, const float* t, const float* h, const float* ps, float alevel, float blevel, int compute,
+                   float* duct, ValuesDefined& fDefined, float undef);
+bool alevelducting(int nx, int ny, const float* t, const float* h, const float* p, int compute, float* duct, ValuesDefined& fDefined, float undef);
+bool hlevelpressure(int nx, int ny, const float* ps, float alevel, float blevel, float* p, ValuesDefined& fDefined, float undef);
+bool pleveldz2tmean(int nx, int ny, const float* z1, const float* z2, float p1, float p2, int compute, float* tmean, ValuesDefined& fDefined, float undef);
+bool kIndex(int nx, int ny, const float* t500, const float* t700, const float* rh700, const float* t850, const float* rh850,
+            float p500, float p700, float p850, int compute, float* kfield, ValuesDefined& fDefined, float undef);
+bool ductingIndex(int nx, int ny, const float* t850, const float* rh850, float p850, int compute, float* duct, ValuesDefined& fDefined, float undef);
+bool showalterIndex(int nx, int ny, const float* t500, const float* t850, const float* rh850, float p500, float p850, int compute,
+                    float* sfield, ValuesDefined& fDefined, float undef);
+bool boydenIndex(int nx, int ny, const float* t700, const float* z700, const float* z1000, float p700, float p1000, int compute,
+                 float* bfield, ValuesDefined& fDefined, float undef);
+bool sweatIndex(int nx, int ny, const float* t850, const float* t500, const float* td850, const float* td500, const float* u850, const float* v850,
+                const float* u500, const float* v500, float* sindex, ValuesDefined& fDefined, float undef);
+bool seaSoundSpeed(int nx, int ny, const float* t, const float* s, float z, int compute, float* soundspeed, ValuesDefined& fDefined, float undef);
+bool cvtemp(int nx, int ny, const float* tinp, int compute, float* tout, ValuesDefined& fDefined, float undef);
+bool abshum(int nx, int ny, const float* t, const float* rhum, float* abshumout, ValuesDefined& fDefined, float undef);
+bool windCooling(int nx, int ny, const float* t, const float* u, const float* v, int compute, float* dtcool, ValuesDefined& fDefined, float undef);
+bool underCooledRain(int nx, int ny, const float* precip, const float* snow, const float* tk, float precipMin, float snowRateMax,
+                     float tcMax, float* undercooled, ValuesDefined& fDefined, float undef);
+bool pressure2FlightLevel(int nx, int ny, const float* pressure, float* flightlevel, ValuesDefined& fDefined, float undef);
+bool snow_in_cm(int nx, int ny, const float* snow_water, const float* tk2m, const float* td2m, float* snow_cm, ValuesDefined& fDefined, float undef);
+bool values2classes(int nx, int ny, const float* fvalue, float* fclass, const std::vector<float>& values, ValuesDefined& fDefined, float undef);
+
+// ---- field algebra ----------------------------------------------------------------
+void minvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, ValuesDefined& fDefined, float undef);
+void minvalueFieldConst(int nx, int ny, const float* field1, const float value, float* fres, ValuesDefined& fDefined, float undef);
+void maxvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, ValuesDefined& fDefined, float undef);
+void maxvalueFieldConst(int nx, int ny, const float* field1, const float value, float* fres, ValuesDefined& fDefined, float undef);
+void absvalueField(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef);
+void log10Field(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef);
+void pow10Field(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef);
+void logField(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef);
+void expField(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef);
+void powerField(int nx, int ny, const float* field, float value, float* fres, ValuesDefined& fDefined, float undef);
+void replaceUndefined(int nx, int ny, const float* field, float value, float* fres, ValuesDefined& fDefined, float undef);
+void replaceDefined(int nx, int ny, const float* field, float value, float* fres, ValuesDefined& fDefined, float undef);
+bool fieldOPERfield(int compute, int nx, int ny, const float* field1, const float* field2, float* fres, ValuesDefined& fDefined, float undef);
+bool fieldOPERconstant(int compute, int nx, int ny, const float* field, float value, float* fres, ValuesDefined& fDefined, float undef);
+bool constantOPERfield(int compute, int nx, int ny, float value, const float* field, float* fres, ValuesDefined& fDefined, float undef);
+
 // ---- extensions of this implementation (not in the reference) -----------------
 // Fused relvort + divergence for nlev levels stored [nlev][ny][nx]; xmapr/ymapr
 // are shared.  fDefined[l] in/out per level.  Either output may be null.
 bool vortdiv_levels(int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
                     float* rvort, float* diverg, std::vector<ValuesDefined>& fDefined, float undef);
+// Declares a host array that is handed to many calls unchanged (xmapr, ymapr,
+// fcoriolis of a grid): uploaded to the calling thread's GPU context once
+// instead of once per call.  Its content must not change until released.
+bool hold_constant_field(const float* field, size_t fsize);
+bool release_constant_field(const float* field);
 // Last error text of the calling thread's GPU context ("" if none).
 const char* last_error();
 

@@ -57,6 +57,16 @@ const char* last_error()
   return mifc_last_error(context());
 }
 
+bool hold_constant_field(const float* field, size_t fsize)
+{
+  return mifc_hold_field(context(), field, fsize) != 0;
+}
+
+bool release_constant_field(const float* field)
+{
+  return mifc_release_field(context(), field) != 0;
+}
+
 void copy_field(float* fout, const float* fin, size_t fsize)
 {
   if (fout != fin)
@@ -212,6 +222,169 @@ bool plevelqvector(int nx, int ny, const float* z, const float* t, const float* 
 {
   FlagIO f(fDefined);
   return mifc_plevelqvector(context(), nx, ny, z, t, xmapr, ymapr, fcoriolis, p, compute, qcomp, f.ptr(), undef, MIFC_MEM_HOST) != 0;
+}
+
+// ---- the rest of the pointwise catalogue: same pattern, one line each --------------
+#define MIFC_FORWARD(call)                    \
+  FlagIO f(fDefined);                         \
+  return (call) != 0
+
+bool plevelthe(int nx, int ny, const float* t, const float* rh, float p, int compute, float* the, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_plevelthe(context(), nx, ny, t, rh, p, compute, the, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool hlevelthe(int nx, int ny, const float* t, const float* q, const float* ps, float alevel, float blevel, int compute, float* the,
+               ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_hlevelthe(context(), nx, ny, t, q, ps, alevel, blevel, compute, the, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool alevelthe(int nx, int ny, const float* t, const float* q, const float* p, int compute, float* the, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_alevelthe(context(), nx, ny, t, q, p, compute, the, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool plevelducting(int nx, int ny, const float* t, const float* h, float p, int compute, float* duct, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_plevelducting(context(), nx, ny, t, h, p, compute, duct, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool hlevelducting(int nx, int ny, const float* t, const float* h, const float* ps, float alevel, float blevel, int compute, float* duct,
+                   ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_hlevelducting(context(), nx, ny, t, h, ps, alevel, blevel, compute, duct, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool alevelducting(int nx, int ny, const float* t, const float* h, const float* p, int compute, float* duct, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_alevelducting(context(), nx, ny, t, h, p, compute, duct, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool hlevelpressure(int nx, int ny, const float* ps, float alevel, float blevel, float* p, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_hlevelpressure(context(), nx, ny, ps, alevel, blevel, p, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool pleveldz2tmean(int nx, int ny, const float* z1, const float* z2, float p1, float p2, int compute, float* tmean, ValuesDefined& fDefined,
+                    float undef)
+{
+  MIFC_FORWARD(mifc_pleveldz2tmean(context(), nx, ny, z1, z2, p1, p2, compute, tmean, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool kIndex(int nx, int ny, const float* t500, const float* t700, const float* rh700, const float* t850, const float* rh850, float p500, float p700,
+            float p850, int compute, float* kfield, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_kIndex(context(), nx, ny, t500, t700, rh700, t850, rh850, p500, p700, p850, compute, kfield, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool ductingIndex(int nx, int ny, const float* t850, const float* rh850, float p850, int compute, float* duct, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_ductingIndex(context(), nx, ny, t850, rh850, p850, compute, duct, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool showalterIndex(int nx, int ny, const float* t500, const float* t850, const float* rh850, float p500, float p850, int compute, float* sfield,
+                    ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_showalterIndex(context(), nx, ny, t500, t850, rh850, p500, p850, compute, sfield, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool boydenIndex(int nx, int ny, const float* t700, const float* z700, const float* z1000, float p700, float p1000, int compute, float* bfield,
+                 ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_boydenIndex(context(), nx, ny, t700, z700, z1000, p700, p1000, compute, bfield, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool sweatIndex(int nx, int ny, const float* t850, const float* t500, const float* td850, const float* td500, const float* u850, const float* v850,
+                const float* u500, const float* v500, float* sindex, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_sweatIndex(context(), nx, ny, t850, t500, td850, td500, u850, v850, u500, v500, sindex, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool seaSoundSpeed(int nx, int ny, const float* t, const float* s, float z, int compute, float* soundspeed, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_seaSoundSpeed(context(), nx, ny, t, s, z, compute, soundspeed, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool cvtemp(int nx, int ny, const float* tinp, int compute, float* tout, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_cvtemp(context(), nx, ny, tinp, compute, tout, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool abshum(int nx, int ny, const float* t, const float* rhum, float* abshumout, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_abshum(context(), nx, ny, t, rhum, abshumout, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool windCooling(int nx, int ny, const float* t, const float* u, const float* v, int compute, float* dtcool, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_windCooling(context(), nx, ny, t, u, v, compute, dtcool, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool underCooledRain(int nx, int ny, const float* precip, const float* snow, const float* tk, float precipMin, float snowRateMax, float tcMax,
+                     float* undercooled, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_underCooledRain(context(), nx, ny, precip, snow, tk, precipMin, snowRateMax, tcMax, undercooled, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool pressure2FlightLevel(int nx, int ny, const float* pressure, float* flightlevel, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_pressure2FlightLevel(context(), nx, ny, pressure, flightlevel, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool snow_in_cm(int nx, int ny, const float* snow_water, const float* tk2m, const float* td2m, float* snow_cm, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_snow_in_cm(context(), nx, ny, snow_water, tk2m, td2m, snow_cm, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool values2classes(int nx, int ny, const float* fvalue, float* fclass, const std::vector<float>& values, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_values2classes(context(), nx, ny, fvalue, fclass, values.data(), static_cast<int>(values.size()), f.ptr(), undef, MIFC_MEM_HOST));
+}
+
+#define MIFC_FORWARD_VOID(call) \
+  FlagIO f(fDefined);           \
+  (void)(call)
+
+void minvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_minvalueFields(context(), nx, ny, field1, field2, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void minvalueFieldConst(int nx, int ny, const float* field1, const float value, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_minvalueFieldConst(context(), nx, ny, field1, value, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void maxvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_maxvalueFields(context(), nx, ny, field1, field2, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void maxvalueFieldConst(int nx, int ny, const float* field1, const float value, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_maxvalueFieldConst(context(), nx, ny, field1, value, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void absvalueField(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_absvalueField(context(), nx, ny, field, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void log10Field(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_log10Field(context(), nx, ny, field, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void pow10Field(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_pow10Field(context(), nx, ny, field, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void logField(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_logField(context(), nx, ny, field, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void expField(int nx, int ny, const float* field, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_expField(context(), nx, ny, field, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void powerField(int nx, int ny, const float* field, float value, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_powerField(context(), nx, ny, field, value, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void replaceUndefined(int nx, int ny, const float* field, float value, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_replaceUndefined(context(), nx, ny, field, value, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+void replaceDefined(int nx, int ny, const float* field, float value, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD_VOID(mifc_replaceDefined(context(), nx, ny, field, value, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool fieldOPERfield(int compute, int nx, int ny, const float* field1, const float* field2, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_fieldOPERfield(context(), compute, nx, ny, field1, field2, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool fieldOPERconstant(int compute, int nx, int ny, const float* field, float value, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_fieldOPERconstant(context(), compute, nx, ny, field, value, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool constantOPERfield(int compute, int nx, int ny, float value, const float* field, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_constantOPERfield(context(), compute, nx, ny, value, field, fres, f.ptr(), undef, MIFC_MEM_HOST));
 }
 
 bool vortdiv_levels(int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr, float* rvort, float* diverg,

@@ -69,11 +69,27 @@ def test_elementwise_device_resident(gpu_ctx, oracle):
         _check_case(gpu_ctx, oracle, case, device=True)
 
 
+def test_catalogue_host_pointers(gpu_ctx, oracle):
+    """theta-e, ducting, indices, conversions, field algebra."""
+    cs = cases.catalogue_cases()
+    assert len(cs) > 1500
+    for case in cs:
+        _check_case(gpu_ctx, oracle, case, device=False)
+
+
+def test_catalogue_device_resident(gpu_ctx, oracle):
+    for case in cases.catalogue_cases(grids=[(17, 9), (64, 48)], modes=("all", "some", "lie")):
+        _check_case(gpu_ctx, oracle, case, device=True)
+
+
 def test_against_golden_vectors(gpu_ctx):
     g, cs = golden_util.stencil_golden_cases()
     for case in cs:
         _check_case(gpu_ctx, None, case, expected=g.expect(case))
     g, cs = golden_util.ewise_golden_cases()
+    for case in cs:
+        _check_case(gpu_ctx, None, case, expected=g.expect(case))
+    g, cs = golden_util.catalogue_golden_cases()
     for case in cs:
         _check_case(gpu_ctx, None, case, expected=g.expect(case))
 
@@ -174,6 +190,57 @@ def test_vortdiv_levels_all_defined_fast_path(gpu_ctx, oracle):
     rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
     (rv, dv), fo = gpu_ctx.vortdiv_levels(u, v, xm, ym, fdefined=flags)
     assert cases.same_bits(rv, rv_e, nan_payload=False) and cases.same_bits(dv, dv_e, nan_payload=False) and np.array_equal(fo, fo_e)
+
+
+@pytest.mark.parametrize("nlev,want", [(21, ("rvort", "diverg")), (18, ("diverg",))])
+def test_vortdiv_levels_host_pipeline(gpu_ctx, oracle, nlev, want, monkeypatch):
+    """A host-resident batch above 64 MiB per field is streamed through the
+    device in chunks (ragged last chunk here); results and flags must equal the
+    whole-batch path and, on sampled levels, the reference's per-level calls."""
+    nx, ny = 1440, 720
+    u, v, xm, ym, flags = _levels_inputs(nx, ny, nlev, 31337)
+    kw = dict(fdefined=flags, want=want)
+    (rv, dv), fo = gpu_ctx.vortdiv_levels(u, v, xm, ym, **kw)
+    monkeypatch.setenv("MIFC_HOST_PIPELINE", "0")
+    (rv0, dv0), fo0 = gpu_ctx.vortdiv_levels(u, v, xm, ym, **kw)
+    assert np.array_equal(fo, fo0)
+    for a, b in ((rv, rv0), (dv, dv0)):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert cases.same_bits(a, b, nan_payload=False)
+    for l in (0, 1, 5, nlev - 2, nlev - 1):
+        ok, o, f = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=int(flags[l]))
+        assert ok and f == fo[l] and cases.same_bits(dv[l], o, nan_payload=False)
+
+
+def test_held_constant_fields(gpu_ctx, oracle):
+    """Map ratios declared constant are uploaded once; results do not change."""
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny = 260, 37
+    xm, ym, fcor = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 5)
+    ok, expect, flag_e = oracle.call("absvort", nx, ny, u, v, xm, ym, fcor, fdefined=SOME)
+    for a in (xm, ym, fcor):
+        gpu_ctx.hold_field(a)
+    try:
+        out, flag = gpu_ctx.absvort(u, v, xm, ym, fcor, fdefined=SOME)
+        assert flag == flag_e and cases.same_bits(out, expect, nan_payload=False)
+        # a changed array must be held again to take effect
+        xm2 = xm.copy()
+        xm[...] = xm * np.float32(2)
+        out_stale, _ = gpu_ctx.absvort(u, v, xm, ym, fcor, fdefined=SOME)
+        assert cases.same_bits(out_stale, expect, nan_payload=False)
+        gpu_ctx.hold_field(xm)
+        ok, expect2, _ = oracle.call("absvort", nx, ny, u, v, xm, ym, fcor, fdefined=SOME)
+        out2, _ = gpu_ctx.absvort(u, v, xm, ym, fcor, fdefined=SOME)
+        assert cases.same_bits(out2, expect2, nan_payload=False)
+        xm[...] = xm2
+    finally:
+        for a in (xm, ym, fcor):
+            gpu_ctx.release_field(a)
+    out3, _ = gpu_ctx.absvort(u, v, xm, ym, fcor, fdefined=SOME)
+    assert cases.same_bits(out3, expect, nan_payload=False)
 
 
 def test_vortdiv_enqueue_counts(gpu_ctx, oracle):

@@ -34,6 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nlev", type=int, default=137)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--only-batched", action="store_true", help="just the pipelined batch (knob sweeps)")
     a = ap.parse_args()
     nx, ny, nlev = 1440, 720, a.nlev
     ctx = fc.Context(0)
@@ -47,9 +48,14 @@ def main():
         res = ctx.vortdiv_levels(u, v, xm, ym, fdefined=[fc.ALL_DEFINED] * nlev, rvort=rv, diverg=dv)
         assert res is not None
 
-    dt = timed(batched, a.reps)
-    print(json.dumps({"case": "vortdiv_levels host pointers", "nlev": nlev, "ms": 1e3 * dt, "mcells_per_s": cells / dt / 1e6,
-                      "link_GBps_each_way": cells * 8 / dt / 1e9}), flush=True)
+    for pipe in ("1",) if a.only_batched else ("1", "0"):
+        os.environ["MIFC_HOST_PIPELINE"] = pipe
+        dt = timed(batched, a.reps)
+        print(json.dumps({"case": "vortdiv_levels host pointers, " + ("chunked full-duplex pipeline" if pipe == "1" else "whole batch staged"),
+                          "nlev": nlev, "ms": 1e3 * dt, "mcells_per_s": cells / dt / 1e6, "link_GBps_each_way": cells * 8 / dt / 1e9}), flush=True)
+    os.environ["MIFC_HOST_PIPELINE"] = "1"
+    if a.only_batched:
+        return
 
     nl = min(nlev, 16)
 
@@ -62,6 +68,14 @@ def main():
     dt = timed(per_field, a.reps)
     print(json.dumps({"case": "relvort + divergence per level, host pointers (legacy call pattern)", "nlev": nl, "ms": 1e3 * dt,
                       "mcells_per_s": nx * ny * nl / dt / 1e6}), flush=True)
+
+    ctx.hold_field(xm)
+    ctx.hold_field(ym)
+    dt = timed(per_field, a.reps)
+    print(json.dumps({"case": "relvort + divergence per level, host pointers, map ratios held on the device", "nlev": nl, "ms": 1e3 * dt,
+                      "mcells_per_s": nx * ny * nl / dt / 1e6}), flush=True)
+    ctx.release_field(xm)
+    ctx.release_field(ym)
 
     u1, v1 = synth.wind(256, 256, 7)
     ff = np.empty_like(u1)
