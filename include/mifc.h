@@ -196,6 +196,12 @@ int mifc_snow_in_cm(mifc_ctx* ctx, int nx, int ny, const float* snow_water, cons
 /* values2classes .h:252 / .cc:2462: `values` (class limits, std::vector<float> there) is always a HOST array */
 int mifc_values2classes(mifc_ctx* ctx, int nx, int ny, const float* fvalue, float* fclass, const float* values, int nvalues, int* fdefined,
                         float undef, int memkind);
+/* vesselIcingOverland .h:238 / FieldCalculationsVesselIcing.cc:77; vesselIcingMertins .h:241 / :114
+ * (vesselIcingModStall .h:244 and vesselIcingMincog .h:248, the two iterative models, are not built yet) */
+int mifc_vesselIcingOverland(mifc_ctx* ctx, int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v,
+                             const float* sal, const float* aice, float* icing, int* fdefined, float undef, int memkind);
+int mifc_vesselIcingMertins(mifc_ctx* ctx, int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v,
+                            const float* sal, const float* aice, float* icing, int* fdefined, float undef, int memkind);
 /* field algebra .h:254-282 / .cc:2501-2669 */
 int mifc_minvalueFields(mifc_ctx* ctx, int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef, int memkind);
 int mifc_maxvalueFields(mifc_ctx* ctx, int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef, int memkind);
@@ -215,6 +221,24 @@ int mifc_fieldOPERconstant(mifc_ctx* ctx, int compute, int nx, int ny, const flo
                            int memkind);
 int mifc_constantOPERfield(mifc_ctx* ctx, int compute, int nx, int ny, float value, const float* field, float* fres, int* fdefined, float undef,
                            int memkind);
+
+/* ---- reductions over ensemble members ---------------------
+ * sumFields .h:284 / .cc:2671; meanValue .h:286 / .cc:2696; stddevValue .h:289 / .cc:2726;
+ * extremeValue .h:292 / .cc:2759; probability .h:294 / .cc:2807.
+ * The reference takes std::vector<float*> fields, std::vector<ValuesDefined>
+ * fDefinedIn and std::vector<float> limits; here `fields` is a HOST array of
+ * nfields pointers (each a host or a device field according to memkind),
+ * `fdefined_in` a HOST int array of nfields flags, `limits` a HOST array.
+ * Members are reduced in index order, like the reference's inner loop. */
+int mifc_sumFields(mifc_ctx* ctx, int nx, int ny, const float* const* fields, int nfields, float* fres, int* fdefined, float undef, int memkind);
+int mifc_meanValue(mifc_ctx* ctx, int nx, int ny, const float* const* fields, const int* fdefined_in, int nfields, float* fres, int* fdefined_out,
+                   float undef, int memkind);
+int mifc_stddevValue(mifc_ctx* ctx, int nx, int ny, const float* const* fields, const int* fdefined_in, int nfields, float* fres,
+                     int* fdefined_out, float undef, int memkind);
+int mifc_extremeValue(mifc_ctx* ctx, int compute, int nx, int ny, const float* const* fields, int nfields, float* fres, int* fdefined, float undef,
+                      int memkind);
+int mifc_probability(mifc_ctx* ctx, int compute, int nx, int ny, const float* const* fields, const int* fdefined_in, int nfields,
+                     const float* limits, int nlimits, float* fres, int* fdefined_out, float undef, int memkind);
 
 /* ---- batched over vertical levels / ensemble members (new surface) ------ */
 /* The reference is called once per 2-D field; a caller that wants vorticity

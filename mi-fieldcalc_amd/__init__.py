@@ -335,6 +335,12 @@ class Context:
         vals = np.ascontiguousarray(values, dtype=np.float32)
         return self._single("mifc_values2classes", [fvalue], [], [out], fdefined, undef, tail=[vals.ctypes.data, int(vals.size)])
 
+    def vesselIcingOverland(self, airtemp, seatemp, u, v, sal, aice, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_vesselIcingOverland", [airtemp, seatemp, u, v, sal, aice], [], [out], fdefined, undef)
+
+    def vesselIcingMertins(self, airtemp, seatemp, u, v, sal, aice, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._single("mifc_vesselIcingMertins", [airtemp, seatemp, u, v, sal, aice], [], [out], fdefined, undef)
+
     def minvalueFields(self, field1, field2, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
         return self._single("mifc_minvalueFields", [field1, field2], [], [out], fdefined, undef)
 
@@ -379,6 +385,46 @@ class Context:
 
     def constantOPERfield(self, compute, value, field, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
         return self._single("mifc_constantOPERfield", [field], [], [out], fdefined, undef, lead=[int(compute)], pre=[float(value)])
+
+    # ---------------------------------- reductions over ensemble members
+    def _ensemble(self, name, fields, fdefined_in, lead, tail, fdefined, undef, out):
+        """fields: sequence of member fields (all numpy or all CUDA tensors)."""
+        fa = [_Arg(f) for f in fields]
+        ref = fields[0] if len(fields) else out
+        if ref is None:
+            raise ValueError("no member fields and no output to take the shape from")
+        nx, ny = self._nxny(_Arg(ref))
+        if out is None:
+            out = _empty_like(ref)
+        oa = _Arg(out)
+        mk = _memkind(fa + [oa])
+        self._bind_stream(mk)
+        table = (ctypes.c_void_p * max(len(fa), 1))(*[a.addr for a in fa])
+        args = list(lead) + [nx, ny, ctypes.addressof(table)]
+        if fdefined_in is not None:
+            flags = (ctypes.c_int * max(len(fa), 1))(*[int(x) for x in fdefined_in])
+            args.append(ctypes.addressof(flags))
+        fd = ctypes.c_int(int(fdefined))
+        args += [len(fa)] + list(tail) + [oa.addr, ctypes.addressof(fd), float(undef), mk]
+        if not self._call(name, args):
+            return None
+        return (out if _is_torch(out) else oa.keep), fd.value
+
+    def sumFields(self, fields, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._ensemble("mifc_sumFields", fields, None, [], [], fdefined, undef, out)
+
+    def meanValue(self, fields, fdefined_in, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._ensemble("mifc_meanValue", fields, fdefined_in, [], [], fdefined, undef, out)
+
+    def stddevValue(self, fields, fdefined_in, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._ensemble("mifc_stddevValue", fields, fdefined_in, [], [], fdefined, undef, out)
+
+    def extremeValue(self, compute, fields, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        return self._ensemble("mifc_extremeValue", fields, None, [int(compute)], [], fdefined, undef, out)
+
+    def probability(self, compute, fields, fdefined_in, limits, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        lim = np.ascontiguousarray(limits, dtype=np.float32)
+        return self._ensemble("mifc_probability", fields, fdefined_in, [int(compute)], [lim.ctypes.data, int(lim.size)], fdefined, undef, out)
 
     # ------------------------------------------------------------------ batched
     def vortdiv_levels(self, u, v, xmapr, ymapr, fdefined=None, undef=UNDEF, rvort=None, diverg=None, want=("rvort", "diverg")):

@@ -90,6 +90,8 @@ SIGNATURES = {
     "mifc_pressure2FlightLevel": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
     "mifc_snow_in_cm": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_values2classes": ("i", ["ctx", "i", "i", "p", "p", "p", "i", "pi", "f", "i"]),
+    "mifc_vesselIcingOverland": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_vesselIcingMertins": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_minvalueFields": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
     "mifc_maxvalueFields": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
     "mifc_minvalueFieldConst": ("i", ["ctx", "i", "i", "p", "f", "p", "pi", "f", "i"]),
@@ -105,6 +107,12 @@ SIGNATURES = {
     "mifc_fieldOPERfield": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "pi", "f", "i"]),
     "mifc_fieldOPERconstant": ("i", ["ctx", "i", "i", "i", "p", "f", "p", "pi", "f", "i"]),
     "mifc_constantOPERfield": ("i", ["ctx", "i", "i", "i", "f", "p", "p", "pi", "f", "i"]),
+    # reductions over ensemble members
+    "mifc_sumFields": ("i", ["ctx", "i", "i", "p", "i", "p", "pi", "f", "i"]),
+    "mifc_meanValue": ("i", ["ctx", "i", "i", "p", "p", "i", "p", "pi", "f", "i"]),
+    "mifc_stddevValue": ("i", ["ctx", "i", "i", "p", "p", "i", "p", "pi", "f", "i"]),
+    "mifc_extremeValue": ("i", ["ctx", "i", "i", "i", "p", "i", "p", "pi", "f", "i"]),
+    "mifc_probability": ("i", ["ctx", "i", "i", "i", "p", "p", "i", "p", "i", "p", "pi", "f", "i"]),
     # batched
     "mifc_vortdiv_levels": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_stencil_levels": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),

@@ -90,6 +90,68 @@ int fill_undef(mifc_ctx* c, int nx, int ny, float* out, int* fdefined, float und
   return 1;
 }
 
+// Per-cell reduction over `nfields` member fields.  Host
+// members are staged next to each other in scratch slot 0; the table of member
+// pointers and the per-member flags live in slot 8.
+int run_ensemble(mifc_ctx* c, mifc::EnsembleParams P, int nx, int ny, const float* const* fields, const int* member_flags, int nfields, float* out,
+                 int* fdefined_out, int memkind, bool may_keep)
+{
+  const long n64 = (long)nx * (long)ny;
+  if (nx < 0 || ny < 0 || n64 > 0x7fffffffL || nfields < 0 || !out || (nfields > 0 && !fields))
+    return 0;
+  const size_t n = (size_t)n64;
+  for (int j = 0; j < nfields; ++j)
+    if (!fields[j])
+      return 0;
+  std::vector<const float*> table((size_t)nfields);
+  if (memkind == MIFC_MEM_HOST) {
+    const size_t stride = (n + 3) & ~size_t(3); // keeps every staged member 16-byte aligned
+    if (nfields > 0 && !ensure_slot(c, 0, (size_t)nfields * stride * sizeof(float)))
+      return 0;
+    for (int j = 0; j < nfields; ++j) {
+      float* d = static_cast<float*>(c->slot[0]) + (size_t)j * stride;
+      MIFC_HIP(c, hipMemcpyAsync(d, fields[j], n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+      table[(size_t)j] = d;
+    }
+  } else {
+    for (int j = 0; j < nfields; ++j)
+      table[(size_t)j] = fields[j];
+  }
+  bool ok = true;
+  P.out = stage_out(c, 9, out, n, memkind, &ok, may_keep);
+  const size_t table_bytes = ((size_t)nfields * sizeof(float*) + 15) & ~size_t(15);
+  if (!ok || !ensure_levels(c, 1) || !ensure_slot(c, 8, table_bytes + (size_t)nfields + 16))
+    return 0;
+  std::vector<unsigned char> flags((size_t)nfields);
+  if (nfields > 0) {
+    MIFC_HIP(c, hipMemcpyAsync(c->slot[8], table.data(), (size_t)nfields * sizeof(float*), hipMemcpyHostToDevice, c->stream));
+    if (member_flags) {
+      for (int j = 0; j < nfields; ++j)
+        flags[(size_t)j] = (unsigned char)member_flags[j];
+      MIFC_HIP(c, hipMemcpyAsync(static_cast<char*>(c->slot[8]) + table_bytes, flags.data(), (size_t)nfields, hipMemcpyHostToDevice, c->stream));
+    }
+  }
+  P.n = (int)n;
+  P.first = 0;
+  P.nfields = nfields;
+  P.fields = static_cast<const float* const*>(c->slot[8]);
+  P.member_flags = member_flags ? reinterpret_cast<const unsigned char*>(static_cast<char*>(c->slot[8]) + table_bytes) : nullptr;
+  P.vector_ok = (reinterpret_cast<size_t>(P.out) & 15u) == 0;
+  for (int j = 0; j < nfields; ++j)
+    P.vector_ok = P.vector_ok && (reinterpret_cast<size_t>(table[(size_t)j]) & 15u) == 0;
+  P.n_undefined = c->d_counts;
+  if (!pinned_acquire(c))
+    return 0;
+  MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64), c->stream));
+  MIFC_HIP(c, mifc::launch_ensemble(P, c->stream));
+  MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  if (!fetch_out(c, 9, out, n, memkind))
+    return 0;
+  MIFC_HIP(c, hipStreamSynchronize(c->stream)); // also: `table` and `flags` were read by their copies
+  *fdefined_out = mifc_classify(pinned_counts(c)[0], (u64)n);
+  return 1;
+}
+
 #define CTX_OR_FAIL(c) \
   if (!(c))            \
     return 0;          \
@@ -494,6 +556,28 @@ int mifc_values2classes(mifc_ctx* c, int nx, int ny, const float* fvalue, float*
   return run_pointwise(c, nx, ny, pc, fclass, fdefined, memkind);
 }
 
+// ------------------------------------------------------------- vessel icing (closed-form models)
+static int vessel_icing(mifc_ctx* c, int model, int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v,
+                        const float* sal, const float* aice, float* icing, int* fdefined, float undef, int memkind)
+{
+  CTX_OR_FAIL(c);
+  PwCall pc = pw_call(mifc::PW_VESSEL_ICING, model, 6, fdefined, undef);
+  const float* in[6] = {airtemp, seatemp, u, v, sal, aice};
+  for (int k = 0; k < 6; ++k)
+    pc.in[k] = in[k];
+  return run_pointwise(c, nx, ny, pc, icing, fdefined, memkind);
+}
+int mifc_vesselIcingOverland(mifc_ctx* c, int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v,
+                             const float* sal, const float* aice, float* icing, int* fdefined, float undef, int memkind)
+{
+  return vessel_icing(c, 1, nx, ny, airtemp, seatemp, u, v, sal, aice, icing, fdefined, undef, memkind);
+}
+int mifc_vesselIcingMertins(mifc_ctx* c, int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v,
+                            const float* sal, const float* aice, float* icing, int* fdefined, float undef, int memkind)
+{
+  return vessel_icing(c, 2, nx, ny, airtemp, seatemp, u, v, sal, aice, icing, fdefined, undef, memkind);
+}
+
 // ------------------------------------------------------------- field algebra
 static int minmax_fields(mifc_ctx* c, int which, int nx, int ny, const float* f1, const float* f2, float* fres, int* fdefined, float undef, int memkind)
 {
@@ -648,6 +732,78 @@ int mifc_constantOPERfield(mifc_ctx* c, int compute, int nx, int ny, float value
   if (compute < 1 || compute > 4)
     return 0;
   return unary_with_constant(c, mifc::PW_CONST_OP_FIELD, compute, nx, ny, field, value, fres, fdefined, undef, memkind, compute == 4);
+}
+
+// ------------------------------------------------------------- ensemble reductions
+static mifc::EnsembleParams ens_params(int op, int compute, float undef)
+{
+  mifc::EnsembleParams P;
+  std::memset(&P, 0, sizeof P);
+  P.op = op;
+  P.compute = compute;
+  P.undef = undef;
+  return P;
+}
+
+int mifc_sumFields(mifc_ctx* c, int nx, int ny, const float* const* fields, int nfields, float* fres, int* fdefined, float undef, int memkind)
+{
+  CTX_OR_FAIL(c);
+  mifc::EnsembleParams P = ens_params(mifc::ENS_SUM, 0, undef);
+  P.all_defined = (*fdefined == MIFC_ALL_DEFINED) ? 1 : 0;
+  return run_ensemble(c, P, nx, ny, fields, nullptr, nfields, fres, fdefined, memkind, false);
+}
+
+int mifc_meanValue(mifc_ctx* c, int nx, int ny, const float* const* fields, const int* fdefined_in, int nfields, float* fres, int* fdefined_out,
+                   float undef, int memkind)
+{
+  CTX_OR_FAIL(c);
+  if (nfields > 0 && !fdefined_in)
+    return 0;
+  return run_ensemble(c, ens_params(mifc::ENS_MEAN, 0, undef), nx, ny, fields, fdefined_in, nfields, fres, fdefined_out, memkind, false);
+}
+
+int mifc_stddevValue(mifc_ctx* c, int nx, int ny, const float* const* fields, const int* fdefined_in, int nfields, float* fres, int* fdefined_out,
+                     float undef, int memkind)
+{
+  CTX_OR_FAIL(c);
+  if (nfields > 0 && !fdefined_in)
+    return 0;
+  return run_ensemble(c, ens_params(mifc::ENS_STDDEV, 0, undef), nx, ny, fields, fdefined_in, nfields, fres, fdefined_out, memkind, false);
+}
+
+int mifc_extremeValue(mifc_ctx* c, int compute, int nx, int ny, const float* const* fields, int nfields, float* fres, int* fdefined, float undef,
+                      int memkind)
+{
+  CTX_OR_FAIL(c);
+  if (nfields == 0) // :2769
+    return 0;
+  mifc::EnsembleParams P = ens_params(mifc::ENS_EXTREME, compute, undef);
+  P.all_defined = (*fdefined == MIFC_ALL_DEFINED) ? 1 : 0;
+  // compute outside 1..4: neither loop runs, nothing is written, the flag becomes ALL_DEFINED (:2803)
+  return run_ensemble(c, P, nx, ny, fields, nullptr, nfields, fres, fdefined, memkind, !(compute >= 1 && compute <= 4));
+}
+
+int mifc_probability(mifc_ctx* c, int compute, int nx, int ny, const float* const* fields, const int* fdefined_in, int nfields, const float* limits,
+                     int nlimits, float* fres, int* fdefined_out, float undef, int memkind)
+{
+  CTX_OR_FAIL(c);
+  if (nfields > 0 && !fdefined_in)
+    return 0;
+  const bool check_between = (nlimits >= 2) && (compute == 3 || compute == 6); // :2821-2825
+  const bool check_above = (nlimits >= 1) && (compute == 1 || compute == 4 || check_between);
+  const bool check_below = (nlimits >= 1) && (compute == 2 || compute == 5 || check_between);
+  if (!(check_above || check_below)) { // :2827-2833: everything undefined, and false
+    int ignored = MIFC_SOME_DEFINED;
+    (void)fill_undef(c, nx, ny, fres, &ignored, undef, memkind);
+    *fdefined_out = MIFC_NONE_DEFINED;
+    return 0;
+  }
+  mifc::EnsembleParams P = ens_params(mifc::ENS_PROBABILITY, compute, undef);
+  P.check_above = check_above ? 1 : 0;
+  P.check_below = check_below ? 1 : 0;
+  P.value_above = limits[0];
+  P.value_below = check_between ? limits[1] : limits[0];
+  return run_ensemble(c, P, nx, ny, fields, fdefined_in, nfields, fres, fdefined_out, memkind, false);
 }
 
 } // extern "C"

@@ -105,7 +105,10 @@ enum PwOp {
   PW_FILL,            // fillUndef :76 and the std::fill branches of replace*
   PW_FIELD_OP_FIELD,  // fieldOPERfield :2611
   PW_FIELD_OP_CONST,  // fieldOPERconstant :2627
-  PW_CONST_OP_FIELD   // constantOPERfield :2647
+  PW_CONST_OP_FIELD,  // constantOPERfield :2647
+  // FieldCalculationsVesselIcing.cc: vesselIcingOverland :77 (compute 1), vesselIcingMertins :114 (2);
+  // in = airtemp, seatemp, u, v, sal, aice
+  PW_VESSEL_ICING
 };
 
 struct PwParams
@@ -131,6 +134,34 @@ struct PwParams
 hipError_t launch_pointwise(const PwParams& prm, hipStream_t stream);
 // sum and number of the defined cells (cvtemp compute 3, 4)
 hipError_t launch_mean_defined(const float* f, int n, int all_defined, float undef, double* sum, unsigned long long* count, hipStream_t stream);
+
+// ------------------------------------ reductions over ensemble members
+enum EnsembleOp {
+  ENS_SUM = 0,        // sumFields :2671
+  ENS_MEAN = 1,       // meanValue :2696
+  ENS_STDDEV = 2,     // stddevValue :2726
+  ENS_EXTREME = 3,    // extremeValue :2759 (compute 1 max, 2 min, 3 index of max, 4 index of min)
+  ENS_PROBABILITY = 4 // probability :2807 (compute 1..3 percent, 4..6 count)
+};
+
+struct EnsembleParams
+{
+  int op;
+  int n;       // cells per member field
+  int first;   // scalar tail launch: first cell
+  int nfields; // members
+  int compute;
+  int all_defined;                    // sumFields / extremeValue: the one input flag
+  const unsigned char* member_flags;  // device u8[nfields] (ValuesDefined of each member) or null
+  int check_above, check_below;       // probability :2821-2823
+  float value_above, value_below;     // :2824-2825
+  int vector_ok;                      // every member field and the output are 16-byte aligned
+  float undef;
+  const float* const* fields; // device table of nfields device pointers
+  float* out;
+  u64* n_undefined;
+};
+hipError_t launch_ensemble(const EnsembleParams& prm, hipStream_t stream);
 
 // -------------------------------------------------------------------- stencils
 enum StencilOp {

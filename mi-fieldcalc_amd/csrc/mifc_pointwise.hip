@@ -60,6 +60,7 @@ PW_TRAITS(PW_FILL, 0, false, false);
 PW_TRAITS(PW_FIELD_OP_FIELD, 2, false, false);
 PW_TRAITS(PW_FIELD_OP_CONST, 1, false, false);
 PW_TRAITS(PW_CONST_OP_FIELD, 1, false, false);
+PW_TRAITS(PW_VESSEL_ICING, 6, false, false);
 #undef PW_TRAITS
 
 // MetConstants.h:46 (rcp, cplr, exl), :53 (ms2knots), :88-90 (flight-level tables)
@@ -374,6 +375,51 @@ __device__ __forceinline__ int pw_point(const PwParams& P, const float* tab, con
     }
     return PW_OK;
   }
+  if (OP == PW_VESSEL_ICING) { // FieldCalculationsVesselIcing.cc:93-104 (Overland), :125-171 (Mertins); x = airtemp, seatemp, u, v, sal, aice
+    if (!((double)x[5] < 0.4))
+      return PW_UNDEF;
+    const double Tf = (-0.002 - 0.0524 * (double)x[4]) - 6.0E-5 * (double)(x[4] * x[4]); // freezing point of sea water, Stallabrass (1980)
+    if ((double)x[1] < Tf)
+      return PW_UNDEF;
+    const double ff = (double)absval(x[2], x[3]);
+    if (P.compute == 1) {
+      const double A = 2.73e-2, B = 2.91e-4, C = 1.84e-6;
+      const double ppr = ff * (Tf - (double)x[0]) / (1 + 0.3 * ((double)x[1] - Tf));
+      r = (float)(A * ppr + B * (ppr * ppr) + C * ppr * ppr * ppr);
+      return PW_OK;
+    }
+    const double temperature = (double)x[0], sst = (double)x[1];
+    r = 0.f;
+    if (ff >= 10.8) {
+      double temp1, temp2, temp3;
+      if (ff < 17.2) {
+        temp1 = -1.15 * sst - 4.3;
+        temp2 = -1.5 * sst - 10;
+        temp3 = -10000;
+      } else if (ff < 20.8) {
+        temp1 = -0.6 * sst - 3.2;
+        temp2 = -1.05 * sst - 5.6;
+        temp3 = -1.75 * sst - 12.5;
+      } else if (ff < 28.5) {
+        temp1 = -0.3 * sst - 2.6;
+        temp2 = -0.66 * sst - 3.32;
+        temp3 = -1.325 * sst - 7.651;
+      } else {
+        temp1 = -0.14 * sst - 2.28;
+        temp2 = -0.3 * sst - 2.6;
+        temp3 = -1.16 * sst - 5.22;
+      }
+      if (temperature > -2)
+        r = 0.f;
+      else if (temperature > temp1)
+        r = (float)0.8333;
+      else if (temperature > temp2)
+        r = (float)2.0833;
+      else
+        r = (temperature <= temp3 || ff < 17.2) ? (float)4.375 : (float)6.25;
+    }
+    return PW_OK;
+  }
   // PW_CONST_OP_FIELD :2655-2664
   switch (P.compute) {
   case 1:
@@ -588,6 +634,7 @@ hipError_t launch_pointwise(const PwParams& prm, hipStream_t stream)
     PW_CASE(PW_FIELD_OP_FIELD);
     PW_CASE(PW_FIELD_OP_CONST);
     PW_CASE(PW_CONST_OP_FIELD);
+    PW_CASE(PW_VESSEL_ICING);
 #undef PW_CASE
   default:
     return hipErrorInvalidValue;

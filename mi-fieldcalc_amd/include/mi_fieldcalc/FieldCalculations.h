@@ -144,6 +144,11 @@ bool pressure2FlightLevel(int nx, int ny, const float* pressure, float* flightle
 bool snow_in_cm(int nx, int ny, const float* snow_water, const float* tk2m, const float* td2m, float* snow_cm, ValuesDefined& fDefined, float undef);
 bool values2classes(int nx, int ny, const float* fvalue, float* fclass, const std::vector<float>& values, ValuesDefined& fDefined, float undef);
 
+bool vesselIcingOverland(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                         const float* aice, float* icing, ValuesDefined& fDefined, float undef);
+bool vesselIcingMertins(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                        const float* aice, float* icing, ValuesDefined& fDefined, float undef);
+
 // ---- field algebra ----------------------------------------------------------------
 void minvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, ValuesDefined& fDefined, float undef);
 void minvalueFieldConst(int nx, int ny, const float* field1, const float value, float* fres, ValuesDefined& fDefined, float undef);
@@ -160,6 +165,16 @@ void replaceDefined(int nx, int ny, const float* field, float value, float* fres
 bool fieldOPERfield(int compute, int nx, int ny, const float* field1, const float* field2, float* fres, ValuesDefined& fDefined, float undef);
 bool fieldOPERconstant(int compute, int nx, int ny, const float* field, float value, float* fres, ValuesDefined& fDefined, float undef);
 bool constantOPERfield(int compute, int nx, int ny, float value, const float* field, float* fres, ValuesDefined& fDefined, float undef);
+
+// ---- reductions over ensemble members ------------------------------------------------
+bool sumFields(int nx, int ny, const std::vector<float*>& fields, float* fres, ValuesDefined& fDefined, float undef);
+bool meanValue(int nx, int ny, const std::vector<float*>& fields, const std::vector<ValuesDefined>& fDefinedIn,
+               float* fres, ValuesDefined& fDefinedOut, float undef);
+bool stddevValue(int nx, int ny, const std::vector<float*>& fields, const std::vector<ValuesDefined>& fDefinedIn,
+                 float* fres, ValuesDefined& fDefinedOut, float undef);
+bool extremeValue(int compute, int nx, int ny, const std::vector<float*>& fields, float* fres, ValuesDefined& fDefined, float undef);
+bool probability(int compute, int nx, int ny, const std::vector<float*>& fields, const std::vector<ValuesDefined>& fDefinedIn,
+                 const std::vector<float>& limits, float* fres, ValuesDefined& fDefinedOut, float undef);
 
 // ---- extensions of this implementation (not in the reference) -----------------
 // Fused relvort + divergence for nlev levels stored [nlev][ny][nx]; xmapr/ymapr

@@ -322,6 +322,17 @@ bool values2classes(int nx, int ny, const float* fvalue, float* fclass, const st
   MIFC_FORWARD(mifc_values2classes(context(), nx, ny, fvalue, fclass, values.data(), static_cast<int>(values.size()), f.ptr(), undef, MIFC_MEM_HOST));
 }
 
+bool vesselIcingOverland(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                         const float* aice, float* icing, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_vesselIcingOverland(context(), nx, ny, airtemp, seatemp, u, v, sal, aice, icing, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool vesselIcingMertins(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                        const float* aice, float* icing, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_vesselIcingMertins(context(), nx, ny, airtemp, seatemp, u, v, sal, aice, icing, f.ptr(), undef, MIFC_MEM_HOST));
+}
+
 #define MIFC_FORWARD_VOID(call) \
   FlagIO f(fDefined);           \
   (void)(call)
@@ -385,6 +396,54 @@ bool fieldOPERconstant(int compute, int nx, int ny, const float* field, float va
 bool constantOPERfield(int compute, int nx, int ny, float value, const float* field, float* fres, ValuesDefined& fDefined, float undef)
 {
   MIFC_FORWARD(mifc_constantOPERfield(context(), compute, nx, ny, value, field, fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+
+// ---- reductions over ensemble members ----------------------------------------------
+namespace {
+std::vector<int> flags_of(const std::vector<ValuesDefined>& v)
+{
+  std::vector<int> f(v.size());
+  for (size_t j = 0; j < v.size(); ++j)
+    f[j] = static_cast<int>(v[j]);
+  return f;
+}
+} // namespace
+
+bool sumFields(int nx, int ny, const std::vector<float*>& fields, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_sumFields(context(), nx, ny, fields.data(), static_cast<int>(fields.size()), fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool meanValue(int nx, int ny, const std::vector<float*>& fields, const std::vector<ValuesDefined>& fDefinedIn, float* fres,
+               ValuesDefined& fDefinedOut, float undef)
+{
+  if (fDefinedIn.size() < fields.size())
+    return false;
+  const std::vector<int> in = flags_of(fDefinedIn);
+  FlagIO f(fDefinedOut);
+  return mifc_meanValue(context(), nx, ny, fields.data(), in.data(), static_cast<int>(fields.size()), fres, f.ptr(), undef, MIFC_MEM_HOST) != 0;
+}
+bool stddevValue(int nx, int ny, const std::vector<float*>& fields, const std::vector<ValuesDefined>& fDefinedIn, float* fres,
+                 ValuesDefined& fDefinedOut, float undef)
+{
+  if (fDefinedIn.size() < fields.size())
+    return false;
+  const std::vector<int> in = flags_of(fDefinedIn);
+  FlagIO f(fDefinedOut);
+  return mifc_stddevValue(context(), nx, ny, fields.data(), in.data(), static_cast<int>(fields.size()), fres, f.ptr(), undef, MIFC_MEM_HOST) != 0;
+}
+bool extremeValue(int compute, int nx, int ny, const std::vector<float*>& fields, float* fres, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_extremeValue(context(), compute, nx, ny, fields.data(), static_cast<int>(fields.size()), fres, f.ptr(), undef, MIFC_MEM_HOST));
+}
+bool probability(int compute, int nx, int ny, const std::vector<float*>& fields, const std::vector<ValuesDefined>& fDefinedIn,
+                 const std::vector<float>& limits, float* fres, ValuesDefined& fDefinedOut, float undef)
+{
+  if (fDefinedIn.size() < fields.size())
+    return false;
+  const std::vector<int> in = flags_of(fDefinedIn);
+  FlagIO f(fDefinedOut);
+  return mifc_probability(context(), compute, nx, ny, fields.data(), in.data(), static_cast<int>(fields.size()), limits.data(),
+                          static_cast<int>(limits.size()), fres, f.ptr(), undef, MIFC_MEM_HOST) != 0;
 }
 
 bool vortdiv_levels(int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr, float* rvort, float* diverg,

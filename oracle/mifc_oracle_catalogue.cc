@@ -683,6 +683,82 @@ int mifcorc_values2classes(int nx, int ny, const float* fvalue, float* fclass, c
       nx * ny, fvalue, fclass, fdefined, undef);
 }
 
+// ------------------------------------------------------------- vessel icing, the two closed-form models
+// FieldCalculationsVesselIcing.cc:77-112 (Overland 1990) and :114-180 (Mertins 1968); temperatures in Celsius
+static int vessel_icing_simple(bool mertins, int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v,
+                               const float* sal, const float* aice, float* icing, int* fdefined, float undef)
+{
+  const int n = nx * ny;
+  const double A = 2.73e-2, B = 2.91e-4, C = 1.84e-6;
+  const bool all = *fdefined == ALL_DEFINED;
+  size_t bad = 0;
+  for (int i = 0; i < n; ++i) {
+    const bool def = all || (defined1(airtemp[i], undef) && defined1(seatemp[i], undef) && defined1(u[i], undef) && defined1(v[i], undef) &&
+                             defined1(sal[i], undef) && defined1(aice[i], undef));
+    bool ok = def && aice[i] < 0.4;
+    if (ok) {
+      const double Tf = (-0.002 - 0.0524 * (double)sal[i]) - 6.0E-5 * (double)(sal[i] * sal[i]); // freezing point of sea water
+      if (seatemp[i] < Tf) {
+        ok = false;
+      } else {
+        const double ff = absval(u[i], v[i]);
+        if (!mertins) {
+          const double ppr = ff * (Tf - (double)airtemp[i]) / (1 + 0.3 * ((double)seatemp[i] - Tf));
+          icing[i] = (float)(A * ppr + B * (ppr * ppr) + C * ppr * ppr * ppr);
+        } else {
+          const double temperature = airtemp[i], sst = seatemp[i];
+          float r = 0;
+          if (ff >= 10.8) {
+            double temp1, temp2, temp3;
+            if (ff < 17.2) {
+              temp1 = -1.15 * sst - 4.3;
+              temp2 = -1.5 * sst - 10;
+              temp3 = -10000;
+            } else if (ff < 20.8) {
+              temp1 = -0.6 * sst - 3.2;
+              temp2 = -1.05 * sst - 5.6;
+              temp3 = -1.75 * sst - 12.5;
+            } else if (ff < 28.5) {
+              temp1 = -0.3 * sst - 2.6;
+              temp2 = -0.66 * sst - 3.32;
+              temp3 = -1.325 * sst - 7.651;
+            } else {
+              temp1 = -0.14 * sst - 2.28;
+              temp2 = -0.3 * sst - 2.6;
+              temp3 = -1.16 * sst - 5.22;
+            }
+            if (temperature > -2)
+              r = 0;
+            else if (temperature > temp1)
+              r = (float)0.8333;
+            else if (temperature > temp2)
+              r = (float)2.0833;
+            else
+              r = (temperature <= temp3 || ff < 17.2) ? (float)4.375 : (float)6.25;
+          }
+          icing[i] = r;
+        }
+      }
+    }
+    if (!ok) {
+      icing[i] = undef;
+      bad += 1;
+    }
+  }
+  *fdefined = classify(bad, n);
+  return 1;
+}
+int mifcorc_vesselIcingOverland(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                                const float* aice, float* icing, int* fdefined, float undef)
+{
+  return vessel_icing_simple(false, nx, ny, airtemp, seatemp, u, v, sal, aice, icing, fdefined, undef);
+}
+int mifcorc_vesselIcingMertins(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                               const float* aice, float* icing, int* fdefined, float undef)
+{
+  return vessel_icing_simple(true, nx, ny, airtemp, seatemp, u, v, sal, aice, icing, fdefined, undef);
+}
+
 // ------------------------------------------------------------- field algebra (:2501-2669)
 int mifcorc_minvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef)
 {

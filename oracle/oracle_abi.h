@@ -110,6 +110,11 @@ int ORC(pressure2FlightLevel)(int nx, int ny, const float* pressure, float* flig
 int ORC(snow_in_cm)(int nx, int ny, const float* snow_water, const float* tk2m, const float* td2m, float* snow_cm, int* fdefined, float undef);
 /* the reference takes std::vector<float> values; here pointer + length */
 int ORC(values2classes)(int nx, int ny, const float* fvalue, float* fclass, const float* values, int nvalues, int* fdefined, float undef);
+/* FieldCalculationsVesselIcing.cc:77 and :114 */
+int ORC(vesselIcingOverland)(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                             const float* aice, float* icing, int* fdefined, float undef);
+int ORC(vesselIcingMertins)(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                            const float* aice, float* icing, int* fdefined, float undef);
 /* field algebra :2501-2669 (the reference's void functions return 1 here) */
 int ORC(minvalueFields)(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef);
 int ORC(maxvalueFields)(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef);

@@ -145,6 +145,17 @@ int mifcref_values2classes(int nx, int ny, const float* fvalue, float* fclass, c
   SHIM(fc::values2classes(nx, ny, fvalue, fclass, v, f.v, undef));
 }
 
+int mifcref_vesselIcingOverland(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                                const float* aice, float* icing, int* fdefined, float undef)
+{
+  SHIM(fc::vesselIcingOverland(nx, ny, airtemp, seatemp, u, v, sal, aice, icing, f.v, undef));
+}
+int mifcref_vesselIcingMertins(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
+                               const float* aice, float* icing, int* fdefined, float undef)
+{
+  SHIM(fc::vesselIcingMertins(nx, ny, airtemp, seatemp, u, v, sal, aice, icing, f.v, undef));
+}
+
 int mifcref_minvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef)
 {
   Flag f(fdefined);

@@ -211,6 +211,13 @@ def catalogue_cases(grids=GRIDS_EWISE, modes=MODES):
         add("underCooledRain", [precip_, snow_, t_, 0.5, 0.3, 1.0])
         add("pressure2FlightLevel", [p3_])
         add("snow_in_cm", [snoww_, t_, td_])
+        # vessel icing: air / sea temperature in Celsius, storm-force winds so that every Mertins class occurs
+        tair = synth.uniform(shape, seed + 30, -25.0, 3.0).astype(np.float32)
+        tsst = synth.uniform(shape, seed + 31, -3.0, 8.0).astype(np.float32)
+        ice = synth.uniform(shape, seed + 32, 0.0, 0.8).astype(np.float32)
+        (tair_, tsst_, ice_), _ = _apply_mode([tair, tsst, ice], mode, seed + 33, _frac(nx, ny))
+        add("vesselIcingOverland", [tair_, tsst_, u_, v_, sal_, ice_])
+        add("vesselIcingMertins", [tair_, tsst_, (u_ * np.float32(1.6)).astype(np.float32) if mode == "all" else u_, v_, sal_, ice_])
         add("values2classes", [anyf_, [-40.0, -10.0, 0.0, 5.0, 20.0, 45.0]])
         add("values2classes", [anyf_, [-40.0, 45.0]], "-two")
         add("values2classes", [anyf_, [1.0]], "-too-few")

@@ -76,6 +76,8 @@ SIGS = {
     "pressure2FlightLevel": "po",
     "snow_in_cm": "pppo",
     "values2classes": "poV",
+    "vesselIcingOverland": "ppppppo",
+    "vesselIcingMertins": "ppppppo",
     "minvalueFields": "ppo",
     "maxvalueFields": "ppo",
     "minvalueFieldConst": "pfo",

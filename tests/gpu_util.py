@@ -33,11 +33,20 @@ def run_gpu(ctx, case, device=False, prefill=None):
     fill = np.float32(-7777.0) if prefill is None else prefill
     outs = [np.full((case["ny"], case["nx"]), fill, dtype=np.float32) for _ in range(n_out)]
     args = list(case["args"])
+    def field(a):
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(case["ny"], case["nx"])
+        return torch.from_numpy(a).cuda() if device else a
+
+    def convert(a):
+        if isinstance(a, np.ndarray):
+            return field(a)
+        if isinstance(a, (list, tuple)) and len(a) and isinstance(a[0], np.ndarray):  # table of ensemble members
+            return [field(x) for x in a]
+        return a
+
+    args = [convert(a) for a in args]
     if device:
-        args = [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(case["ny"], case["nx"])).cuda() if isinstance(a, np.ndarray) else a for a in args]
         outs = [torch.from_numpy(o).cuda() for o in outs]
-    else:
-        args = [np.ascontiguousarray(a, dtype=np.float32).reshape(case["ny"], case["nx"]) if isinstance(a, np.ndarray) else a for a in args]
     fn = getattr(ctx, op)
     out_kw = tuple(outs) if n_out == 2 else outs[0]
     res = fn(*args, fdefined=case["fdefined"], undef=case["undef"], out=out_kw)

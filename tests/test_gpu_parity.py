@@ -82,7 +82,70 @@ def test_catalogue_device_resident(gpu_ctx, oracle):
         _check_case(gpu_ctx, oracle, case, device=True)
 
 
+def test_python_surface_matches_reference_module(gpu_ctx, oracle):
+    """mi_fieldcalc.py mirrors python/py_mi_fieldcalc.cc: the reference's own Python
+    test (python/test_mi_fieldcalc.py:36-41: abshum(293.16 K, 0.8) = 13.83 +- 0.02),
+    None on shape mismatch / non-2-D input / failing operator, float32 result."""
+    import mi_fieldcalc as pyfc
+
+    ah = pyfc.abshum(np.array([[293.16]]), np.array([[0.8]]), -1)
+    assert ah is not None and ah.dtype == np.float32 and ah.shape == (1, 1)
+    assert abs(float(ah[0, 0]) - 13.83) <= 0.02
+    assert int(pyfc.ValuesDefined.SOME_DEFINED) == 2
+    t = np.full((6, 5), 280.0)
+    assert pyfc.cvtemp(t, 1, 1e35).shape == (6, 5)
+    assert pyfc.cvtemp(t[0], 1, 1e35) is None  # not 2-D
+    assert pyfc.abshum(t, t[:3], 1e35) is None  # shapes differ
+    assert pyfc.cvtemp(t, 9, 1e35) is None  # operator returns false
+    rh = np.full((6, 5), 55.0)
+    td = pyfc.cvhum(t, rh, "kelvin", 1, 1e35)
+    ok, expect, _ = oracle.call("cvhum", 5, 6, t.astype(np.float32), rh.astype(np.float32), "kelvin", 1, fdefined=SOME)
+    assert ok and cases.same_bits(td, expect)
+    for name in ("kIndex", "ductingIndex", "showalterIndex", "boydenIndex", "sweatIndex", "seaSoundSpeed", "cvtemp", "cvhum", "abshum",
+                 "windCooling", "underCooledRain", "vesselIcingOverland", "vesselIcingMertins", "vesselIcingModStall", "vesselIcingMincog"):
+        assert callable(getattr(pyfc, name))  # the 15 functions of py_mi_fieldcalc.cc:189-207
+    with pytest.raises(NotImplementedError):
+        pyfc.vesselIcingMincog(*([t] * 11), 5.0, 0.5, 1.0, 4.0, 1, 1e35)
+
+
+def test_ensemble_reductions(gpu_ctx, oracle):
+    """sum / mean / stddev / extreme / probability over members, bit-exact
+    (the members are reduced in index order, like the reference's inner loop)."""
+    cs = cases.ensemble_cases()
+    assert len(cs) > 400
+    for case in cs:
+        _check_case(gpu_ctx, oracle, case, device=False)
+    for case in cases.ensemble_cases(grids=((17, 9), (64, 48)), modes=("all", "some")):
+        _check_case(gpu_ctx, oracle, case, device=True)
+
+
+def test_ensemble_51_members_full_field(gpu_ctx, oracle):
+    """BASELINE.json config 5 has 51 members: one 1440x720 level of them, device resident."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nmem = 1440, 720, 51
+    members = [synth.uniform((ny, nx), 4000 + k, -5.0, 30.0).astype(np.float32) for k in range(nmem)]
+    members[7] = synth.sprinkle_undef(members[7], 1, 0.01)
+    flags = [ALL] * nmem
+    flags[7] = SOME
+    dm = [torch.from_numpy(m).cuda() for m in members]
+    for op, args_cpu, call in (
+        ("meanValue", [members, flags], lambda: gpu_ctx.meanValue(dm, flags)),
+        ("stddevValue", [members, flags], lambda: gpu_ctx.stddevValue(dm, flags)),
+        ("probability", [1, members, flags, [20.0]], lambda: gpu_ctx.probability(1, dm, flags, [20.0])),
+        ("extremeValue", [3, members], lambda: gpu_ctx.extremeValue(3, dm, fdefined=SOME)),
+    ):
+        ok, expect, flag_e = oracle.call(op, nx, ny, *args_cpu, fdefined=SOME)
+        out, flag = call()
+        assert ok and flag == flag_e and cases.same_bits(out.cpu().numpy(), expect, nan_payload=False), op
+
+
 def test_against_golden_vectors(gpu_ctx):
+    g, cs = golden_util.ensemble_golden_cases()
+    for case in cs:
+        _check_case(gpu_ctx, None, case, expected=g.expect(case))
     g, cs = golden_util.stencil_golden_cases()
     for case in cs:
         _check_case(gpu_ctx, None, case, expected=g.expect(case))
