@@ -134,15 +134,28 @@ __global__ __launch_bounds__(256) void ensemble_kernel(const EnsembleParams P)
         ens_init<OP>(P, a[c]);
         live[c] = true;
       }
-      for (int j = 0; j < P.nfields; ++j) {
-        const float4 v = reinterpret_cast<const float4*>(P.fields[j])[q];
-        const unsigned char fl = P.member_flags ? P.member_flags[j] : (unsigned char)(P.all_defined ? 0 : 2);
-        const bool m_all = fl == 0, m_none = fl == 1;
-        const float f[4] = {v.x, v.y, v.z, v.w};
+      // members in groups of MB: all loads of a group are issued before the first
+      // is consumed (the accumulation itself stays in member order)
+      constexpr int MB = 8;
+      for (int j0 = 0; j0 < P.nfields; j0 += MB) {
+        float4 v[MB];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (live[c])
-            live[c] = ens_member<OP>(P, a[c], j, f[c], m_all, m_none);
+        for (int k = 0; k < MB; ++k)
+          if (j0 + k < P.nfields)
+            v[k] = reinterpret_cast<const float4*>(P.fields[j0 + k])[q];
+#pragma unroll
+        for (int k = 0; k < MB; ++k) {
+          if (j0 + k < P.nfields) {
+            const int j = j0 + k;
+            const unsigned char fl = P.member_flags ? P.member_flags[j] : (unsigned char)(P.all_defined ? 0 : 2);
+            const bool m_all = fl == 0, m_none = fl == 1;
+            const float f[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (live[c])
+                live[c] = ens_member<OP>(P, a[c], j, f[c], m_all, m_none);
+          }
+        }
       }
       if (keep_all)
         continue;

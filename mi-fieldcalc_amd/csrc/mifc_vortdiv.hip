@@ -70,6 +70,8 @@ struct RowsParams
   int xcd_remap;       // 1: sequence = (b % 8) * per_xcd + b / 8
   int zigzag;          // 1: odd bands walk upwards
   int nt_interior;     // 1: rows no other band touches are loaded nontemporally
+  int exp_nohalo;      // MEASUREMENT ONLY (wrong results): halo rows are not fetched, to price their traffic
+  int exp_nostore;     // MEASUREMENT ONLY: 1 = only lane-0-of-wave-0-like sliver of the stores is issued (read side alone)
   long idx_lo, idx_hi; // valid flat element range relative to owned row 0 (for clamped scalar loads)
   const float *u, *v, *xm, *ym;
   const float* fc; // coriolis parameter, absvort only
@@ -149,7 +151,7 @@ __device__ __forceinline__ void decode_block(const RowsParams& P, int seq, int& 
 }
 
 template <bool CHECK, bool WANT_V, bool WANT_D, bool ABSV, int D, bool NT, int V>
-__global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
+__global__ __launch_bounds__(256) void vortdiv_rows_kernel(const RowsParams P)
 {
   constexpr int W = D + 3;    // ring slots: rows r-2 (being refilled), r-1, r, r+1, r+2 .. r+D
   constexpr int WCOLS = 256 * V; // columns per wave
@@ -208,7 +210,9 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
   const bool up = (P.zigzag != 0) && ((band & 1) != 0);
   // step t in [-1, nr] of the walk -> local row; steps past the far halo are clamped to it
   auto load_row = [&](int t) -> RowRegs<V> {
-    const int tc = t > nr ? nr : t;
+    int tc = t > nr ? nr : t;
+    if (P.exp_nohalo)
+      tc = tc < 0 ? 0 : (tc > nr - 1 ? nr - 1 : tc);
     const int rowl = up ? (nr - 1 - tc) : tc;
     const long base = (long)(jb + rowl) * nx;
     const bool stream_row = P.nt_interior && tc >= 1 && tc <= nr - 2;
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(1024) void vortdiv_rows_kernel(const RowsParams P)
           zv[3] = zv[2];
           zd[3] = zd[2];
         }
-        if (actq[q]) {
+        if (actq[q] && !(P.exp_nostore && zv[0] != 12345.678f)) {
           const long o = (long)jl * nx + colq[q];
           if (WANT_V) {
             v4f z4;
@@ -383,8 +387,131 @@ level_done:
     wave_count_add(P.n_undefined + lev, bad);
 }
 
+// ---------------------------------------------------------------------------
+// One-shot form of the same operator (tuning K=1): no row loop.  A workgroup is
+// 4 waves = 4 consecutive rows x 256 columns of one level; every lane loads the
+// float4 of its own row and of the rows above and below (6 loads of 16 B, all
+// issued at once), the map factors (2 loads), takes its x neighbours from the
+// adjacent lanes (DPP) and stores.  Each value is requested three times, but
+// two of the three requests hit in L1 / L2 (the rows are shared inside the
+// workgroup and with the next row block on the same XCD); in exchange every
+// wave has its whole traffic in flight at once and lives for one memory
+// round trip, like a streaming copy.
+template <bool CHECK, bool WANT_V, bool WANT_D, bool NT>
+__global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P)
+{
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int bid = blockIdx.x;
+  const int seq = P.xcd_remap ? ((bid & 7) * P.per_xcd + (bid >> 3)) : bid;
+  if (seq >= P.n_logical)
+    return;
+  // address order: column segment fastest, then row block, then level
+  const int per_level = P.uB * P.uW;
+  const int lev = seq / per_level;
+  const int rem = seq - lev * per_level;
+  const int rblock = rem / P.uW;
+  const int wc = rem - rblock * P.uW;
+
+  const int nx = P.nx;
+  const int jl = P.lo + rblock * 4 + wave; // local row of this wave
+  if (jl >= P.hi)
+    return;
+  const int j = P.j0 + jl;
+  const int col = wc * 256 + lane * 4;
+  const bool act = col < nx;
+  const int col_c = act ? col : nx - 4;
+  int east_col = wc * 256 + 256;
+  if (east_col > nx)
+    east_col = nx;
+  const int edge_col = (lane == 63) ? east_col : (wc * 256 - 1);
+  const float undef = P.undef;
+  const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
+
+  const float* __restrict__ u = P.u + (size_t)lev * P.in_stride;
+  const float* __restrict__ v = P.v + (size_t)lev * P.in_stride;
+  const long base = (long)jl * nx;
+  const long o = base + col_c;
+  const v4f uc = load4(u + o), vc = load4(v + o);
+  const v4f un = load4(u + o + nx), us = load4(u + o - nx);
+  const v4f vn = load4(v + o + nx), vs = load4(v + o - nx);
+  const v4f xm4 = load4(P.xm + o), ym4 = load4(P.ym + o);
+  long e = base + edge_col;
+  e = e < P.idx_lo ? P.idx_lo : (e > P.idx_hi ? P.idx_hi : e);
+  const float eu = u[e], ev = v[e];
+
+  const float east_u = readlane_f(eu, 63), east_v = readlane_f(ev, 63);
+  float uW = dpp_from_lower_lane(eu, uc.w), vW = dpp_from_lower_lane(ev, vc.w);
+  float uE = dpp_from_upper_lane(eu, uc.x), vE = dpp_from_upper_lane(ev, vc.x);
+  if (col + 4 >= east_col) {
+    uE = east_u;
+    vE = east_v;
+  }
+  const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
+  const float vcx[6] = {vW, vc.x, vc.y, vc.z, vc.w, vE};
+  float zv[4], zd[4];
+  unsigned int bad = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float vw = vcx[k], ve = vcx[k + 2], uw = ucx[k], ue = ucx[k + 2];
+    bool ok = true;
+    if (CHECK)
+      ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef)); // :1861, :1927
+    zv[k] = 0.f;
+    zd[k] = 0.f;
+    if (WANT_V)
+      zv[k] = ok ? f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]) : undef;
+    if (WANT_D)
+      zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]) : undef;
+    if (CHECK && !ok && act)
+      bad += 1;
+  }
+  if (col == 0) { // fillEdges, column part (:65-68)
+    zv[0] = zv[1];
+    zd[0] = zd[1];
+  }
+  if (col + 4 == nx) {
+    zv[3] = zv[2];
+    zd[3] = zd[2];
+  }
+  if (act) {
+    const bool top = (j == 1) && (P.j0 == 0);
+    const bool bottom = (j == P.nyg - 2) && (P.j0 + P.ny_local == P.nyg);
+    const long oo = base + col;
+    if (WANT_V) {
+      float* rv = P.rv + (size_t)lev * P.out_stride;
+      v4f z4;
+      z4.x = zv[0];
+      z4.y = zv[1];
+      z4.z = zv[2];
+      z4.w = zv[3];
+      store4<NT>(rv + oo, z4);
+      if (top) // fillEdges, row part (:70-73)
+        store4<NT>(rv + oo - nx, z4);
+      if (bottom)
+        store4<NT>(rv + oo + nx, z4);
+    }
+    if (WANT_D) {
+      float* dv = P.dv + (size_t)lev * P.out_stride;
+      v4f d4;
+      d4.x = zd[0];
+      d4.y = zd[1];
+      d4.z = zd[2];
+      d4.w = zd[3];
+      store4<NT>(dv + oo, d4);
+      if (top)
+        store4<NT>(dv + oo - nx, d4);
+      if (bottom)
+        store4<NT>(dv + oo + nx, d4);
+    }
+  }
+  if (CHECK && P.n_undefined)
+    wave_count_add(P.n_undefined + lev, bad);
+}
+
 struct Tuning
 {
+  int K;     // 0: row-walking kernel (default), 1: one-shot kernel
   int R;     // rows per band
   int D;     // rows kept in flight beyond the 3-row window (0 or 1)
   int NT;    // nontemporal stores
@@ -394,6 +521,9 @@ struct Tuning
   int WPB;   // waves per workgroup: 4, 8 or 16 (levels side by side)
   int ZZ;    // odd bands walk upwards (halo rows meet in L2)
   int NTI;   // nontemporal loads for the rows of a band that no other band reads
+  int XH;    // measurement only: skip the halo rows (results are wrong), never set by the library itself
+  int XS;    // measurement only: skip (practically all) stores
+  int PADROWS; // measurement only: the last PADROWS rows of every level are padding (changes the level stride)
 };
 
 int tune_value(const char* s, const char* key, int dflt)
@@ -412,9 +542,10 @@ int tune_value(const char* s, const char* key, int dflt)
 
 Tuning current_tuning(int nx)
 {
-  Tuning t = {8, 1, 1, 2, 1, 1, 4, 1, 0};
+  Tuning t = {0, 6, 1, 1, 2, 1, 1, 4, 1, 0, 0, 0, 0}; // R=6: 120 bands of 6 rows tile the 718 computed rows of a 720-row field almost exactly and measured ~1 % ahead of R=8
   // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,V=2,ORDER=1,XCD=1,WPB=8" -- used by the sweep tool and the tests
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
+    t.K = tune_value(s, "K", t.K);
     t.R = tune_value(s, "R", t.R);
     t.D = tune_value(s, "D", t.D);
     t.NT = tune_value(s, "NT", t.NT);
@@ -424,10 +555,13 @@ Tuning current_tuning(int nx)
     t.WPB = tune_value(s, "WPB", t.WPB);
     t.ZZ = tune_value(s, "ZZ", t.ZZ);
     t.NTI = tune_value(s, "NTI", t.NTI);
+    t.XH = tune_value(s, "XH", 0);
+    t.XS = tune_value(s, "XS", 0);
+    t.PADROWS = tune_value(s, "PADROWS", 0);
   }
-  if (t.WPB != 1 && t.WPB != 2 && t.WPB != 4 && t.WPB != 8 && t.WPB != 16)
-    t.WPB = 8;
-  if (t.V != 1 && t.V != 2)
+  if (t.WPB != 1 && t.WPB != 2 && t.WPB != 4)
+    t.WPB = 4; // the kernel is compiled for workgroups of up to 4 waves (8 and 16 were measured: no gain)
+  if (t.V != 1 && t.V != 2 && t.V != 3)
     t.V = 2;
   if (nx <= 256)
     t.V = 1; // a second 256-column segment would be empty
@@ -438,8 +572,8 @@ Tuning current_tuning(int nx)
     t.R = rmax;
   if (t.D < 0)
     t.D = 0;
-  if (t.D > 1)
-    t.D = 1; // deeper rings were measured (no gain) and are not instantiated
+  if (t.D > 3)
+    t.D = 3;
   return t;
 }
 
@@ -449,6 +583,8 @@ void launch_v(const RowsParams& rp, const Tuning& t, int grid, hipStream_t strea
   const size_t lds = (size_t)rp.R * 1024 * t.V * (ABSV ? 3 : 2);
   if (t.V == 2)
     hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, ABSV, D, NT, 2>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
+  else if (t.V == 3)
+    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, ABSV, D, NT, 3>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
   else
     hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, ABSV, D, NT, 1>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
 }
@@ -456,19 +592,22 @@ void launch_v(const RowsParams& rp, const Tuning& t, int grid, hipStream_t strea
 template <bool CHECK, bool WV, bool WD, bool ABSV>
 void launch_d(const RowsParams& rp, const Tuning& t, int grid, hipStream_t stream)
 {
-  const int sel = (t.D > 0 ? 1 : 0) | (t.NT ? 2 : 0);
-  switch (sel) {
-  case 0:
-    launch_v<CHECK, WV, WD, ABSV, 0, false>(rp, t, grid, stream);
-    break;
-  case 1:
+  if (!t.NT) { // plain stores: only the default depth is instantiated
     launch_v<CHECK, WV, WD, ABSV, 1, false>(rp, t, grid, stream);
-    break;
-  case 2:
+    return;
+  }
+  switch (t.D) {
+  case 0:
     launch_v<CHECK, WV, WD, ABSV, 0, true>(rp, t, grid, stream);
     break;
-  default:
+  case 1:
     launch_v<CHECK, WV, WD, ABSV, 1, true>(rp, t, grid, stream);
+    break;
+  case 2:
+    launch_v<CHECK, WV, WD, ABSV, 2, true>(rp, t, grid, stream);
+    break;
+  default:
+    launch_v<CHECK, WV, WD, ABSV, 3, true>(rp, t, grid, stream);
     break;
   }
 }
@@ -532,12 +671,12 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     t.WPB /= 2; // fewer levels than waves: do not launch waves that only stage map factors
   RowsParams rp;
   rp.nx = nx;
-  rp.nyg = prm.ny_global;
+  rp.nyg = prm.ny_global - t.PADROWS;
   rp.j0 = prm.j0;
-  rp.ny_local = prm.ny_local;
+  rp.ny_local = prm.ny_local - t.PADROWS;
   rp.lo = (prm.j0 >= 1) ? 0 : (1 - prm.j0);
-  const int last = prm.ny_global - 1 - prm.j0; // local index of the global last row
-  rp.hi = (prm.ny_local < last) ? prm.ny_local : last;
+  const int last = rp.nyg - 1 - prm.j0; // local index of the global last row
+  rp.hi = (rp.ny_local < last) ? rp.ny_local : last;
   if (rp.hi <= rp.lo) {
     // slab without a single computed row (can only be a 1-row edge slab): not supported here
     return hipSuccess;
@@ -545,9 +684,9 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   // A row slab carries one halo row before owned row 0 and one after the last
   // owned row; a whole field has neither.
   const bool has_north_halo = prm.j0 > 0;
-  const bool has_south_halo = prm.j0 + prm.ny_local < prm.ny_global;
+  const bool has_south_halo = prm.j0 + rp.ny_local < rp.nyg;
   rp.idx_lo = has_north_halo ? -(long)nx : 0;
-  rp.idx_hi = (long)nx * (prm.ny_local + (has_south_halo ? 1 : 0)) - 1;
+  rp.idx_hi = (long)nx * (rp.ny_local + (has_south_halo ? 1 : 0)) - 1;
   rp.R = t.R;
   rp.nbands = (rp.hi - rp.lo + t.R - 1) / t.R;
   rp.nwc = (nx + 256 * t.V - 1) / (256 * t.V);
@@ -565,6 +704,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.xcd_remap = t.XCD;
   rp.zigzag = t.ZZ;
   rp.nt_interior = t.NTI;
+  rp.exp_nohalo = t.XH;
+  rp.exp_nostore = t.XS;
   rp.u = prm.f0;
   rp.v = prm.f1;
   rp.xm = prm.xmapr;
@@ -577,9 +718,43 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.all_defined = prm.all_defined;
   rp.undef = prm.undef;
   rp.n_undefined = prm.n_undefined;
-  const int grid = rp.per_xcd * 8;
+  int grid = rp.per_xcd * 8;
 
   *handled = true;
+  if (t.K == 1 && !rp.fc) { // one-shot form: units are (level, block of 4 rows, 256-column segment)
+    rp.uB = (rp.hi - rp.lo + 3) / 4;
+    rp.uW = (nx + 255) / 256;
+    const long units = (long)prm.nlev * rp.uB * rp.uW;
+    if (units <= 0x3fffffffL) {
+      rp.n_logical = (int)units;
+      rp.per_xcd = (rp.n_logical + 7) / 8;
+      grid = rp.per_xcd * 8;
+      const bool chk = !prm.every_level_all_defined;
+      const int sel = (chk ? 4 : 0) | (rv ? 2 : 0) | (dv ? 1 : 0);
+      switch (sel) {
+#define ONESHOT(C, WV, WD) \
+  if (t.NT) \
+    hipLaunchKernelGGL((vortdiv_oneshot_kernel<C, WV, WD, true>), dim3(grid), dim3(256), 0, stream, rp); \
+  else \
+    hipLaunchKernelGGL((vortdiv_oneshot_kernel<C, WV, WD, false>), dim3(grid), dim3(256), 0, stream, rp); \
+  break
+      case 1:
+        ONESHOT(false, false, true);
+      case 2:
+        ONESHOT(false, true, false);
+      case 3:
+        ONESHOT(false, true, true);
+      case 5:
+        ONESHOT(true, false, true);
+      case 6:
+        ONESHOT(true, true, false);
+      default:
+        ONESHOT(true, true, true);
+#undef ONESHOT
+      }
+      return hipGetLastError();
+    }
+  }
   if (prm.every_level_all_defined)
     launch_outputs<false>(rp, t, grid, stream);
   else

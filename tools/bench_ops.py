@@ -120,6 +120,56 @@ def main():
     add("fused ff+RH+theta (hybrid)", 28, 4 * n, lambda: ctx.hlevel_derived_levels(u, v, t, q, ps, a, b, fdef_wind=flags, fdef_thermo=flags,
                                                                                     out={"ff": out, "rh": out2, "theta": o_t.reshape(NLEV, NY, NX)}),
         "hlevelhum", [h["t"], h["q"], h["ps"], 12.5, 0.73, "kelvin", 1])
+    # ---- the rest of the stencil family, on the batch seen as one tall field
+    xm_t, ym_t, fc_t = (x.repeat(NLEV, 1).contiguous() for x in (dxm, dym, dfc))
+    ALLD = fc.ALL_DEFINED
+    add("advection", 24, 0, lambda: ctx.advection(tall(z), tall(u), tall(v), xm_t, ym_t, 1.0, fdefined=ALLD, out=o_t), "advection",
+        [h["z"], h["u"], h["v"], xm, ym, 1.0])
+    add("jacobian", 20, 0, lambda: ctx.jacobian(tall(z), tall(u), xm_t, ym_t, fdefined=ALLD, out=o_t), "jacobian", [h["z"], h["u"], xm, ym])
+    add("thermalFrontParameter (2 passes)", 16, 0, lambda: ctx.thermalFrontParameter(tall(t), xm_t, ym_t, fdefined=ALLD, out=o_t),
+        "thermalFrontParameter", [h["t"], xm, ym])
+    add("plevelqvector (3 passes)", 24, 0, lambda: ctx.plevelqvector(tall(z), tall(t), xm_t, ym_t, fc_t, 500.0, 1, fdefined=ALLD, out=o_t),
+        "plevelqvector", [h["z"], h["t"], xm, ym, fcor, 500.0, 1])
+    # ---- 8f-3: pointwise catalogue
+    t2 = (t - 20.0).contiguous()
+    t3, t4, rh2, u2, v2 = (t - 8.0).contiguous(), (t - 28.0).contiguous(), (rh * 0.9).contiguous(), (u * 0.5).contiguous(), (v * 0.5).contiguous()
+    add("plevelthe c=1", 12, 0, lambda: ctx.plevelthe(tall(t), tall(rh), 850.0, 1, fdefined=ALLD, out=o_t), "plevelthe", [h["t"], h["rh"], 850.0, 1])
+    add("hlevelthe c=1", 16, 0, lambda: ctx.hlevelthe(tall(t), tall(q), ps_tall, 12.5, 0.73, 1, fdefined=ALLD, out=o_t), "hlevelthe",
+        [h["t"], h["q"], h["ps"], 12.5, 0.73, 1])
+    add("kIndex", 24, 0, lambda: ctx.kIndex(tall(t2), tall(t3), tall(rh2), tall(t), tall(rh), 500.0, 700.0, 850.0, 1, fdefined=ALLD, out=o_t), "kIndex",
+        [h["t"] - 20, h["t"], h["rh"], h["t"], h["rh"], 500.0, 700.0, 850.0, 1])
+    add("showalterIndex", 16, 0, lambda: ctx.showalterIndex(tall(t2), tall(t), tall(rh), 500.0, 850.0, 1, fdefined=ALLD, out=o_t), "showalterIndex",
+        [h["t"] - 20, h["t"], h["rh"], 500.0, 850.0, 1])
+    add("sweatIndex", 36, 0, lambda: ctx.sweatIndex(tall(t), tall(t2), tall(t3), tall(t4), tall(u), tall(v), tall(u2), tall(v2), fdefined=ALLD, out=o_t),
+        "sweatIndex", [h["t"], h["t"] - 20, h["t"], h["t"] - 20, h["u"], h["v"], h["v"], h["u"]])
+    add("abshum", 12, 0, lambda: ctx.abshum(tall(t), tall(rh), fdefined=ALLD, out=o_t), "abshum", [h["t"], h["rh"]])
+    add("windCooling", 16, 0, lambda: ctx.windCooling(tall(t), tall(u), tall(v), 1, fdefined=ALLD, out=o_t), "windCooling", [h["t"], h["u"], h["v"], 1])
+    add("cvtemp c=1", 8, 0, lambda: ctx.cvtemp(tall(t), 1, fdefined=ALLD, out=o_t), "cvtemp", [h["t"], 1])
+    add("fieldOPERfield +", 12, 0, lambda: ctx.fieldOPERfield(1, tall(t), tall(q), fdefined=ALLD, out=o_t), "fieldOPERfield", [1, h["t"], h["q"]])
+    add("log10Field", 8, 0, lambda: ctx.log10Field(tall(t), fdefined=ALLD, out=o_t), "log10Field", [h["t"]])
+    # ---- 8f-4: reductions over the batch's levels taken as ensemble members of one 1440x720 field
+    nm = min(NLEV, 51)
+    members = [t[k] for k in range(nm)]
+    hm = [t[k].cpu().numpy() for k in range(min(nm, 8))]
+    o1 = out[0]
+
+    def add_ens(name, gpu_fn, cpu_op, cpu_args):
+        ms = gpu_time(gpu_fn)
+        alg = n * 4 * (nm + 1)
+        t0 = time.perf_counter()
+        cpu.call(cpu_op, NX, NY, *cpu_args, fdefined=fc.ALL_DEFINED)
+        cr = n * len(hm) / (time.perf_counter() - t0) / 1e6
+        rec = {"op": name, "ms": round(ms, 4), "Mcells_per_s": round(n * nm / ms / 1e3, 1), "algorithmic_bytes": alg, "GBps": round(alg / ms / 1e6, 1),
+               "frac_of_8TBps": round(alg / ms / 1e6 / PEAK, 4), "cpu_Mcells_per_s_1core": round(cr, 1),
+               "cpu_kind": "reference" if which == "ref" else "port", "nlev": nm}
+        rows.append(rec)
+        print(json.dumps(rec), flush=True)
+
+    mflags = [fc.ALL_DEFINED] * nm
+    add_ens("meanValue (%d members)" % nm, lambda: ctx.meanValue(members, mflags, out=o1), "meanValue", [hm, mflags[:len(hm)]])
+    add_ens("stddevValue (%d members)" % nm, lambda: ctx.stddevValue(members, mflags, out=o1), "stddevValue", [hm, mflags[:len(hm)]])
+    add_ens("probability>280 (%d members)" % nm, lambda: ctx.probability(1, members, mflags, [280.0], out=o1), "probability",
+            [1, hm, mflags[:len(hm)], [280.0]])
     print()
     print("%-30s %9s %12s %9s %7s %14s" % ("operator (1440x720x%d)" % NLEV, "GPU ms", "Mcells/s", "GB/s", "frac", "CPU Mcells/s"))
     for r in rows:
