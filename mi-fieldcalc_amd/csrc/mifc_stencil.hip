@@ -264,7 +264,7 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
 {
   if (prm.nlev <= 0)
     return hipSuccess;
-  if (prm.op == ST_VORTDIV || prm.op == ST_RELVORT || prm.op == ST_DIVERGENCE || prm.op == ST_ABSVORT) {
+  if (prm.op == ST_VORTDIV || prm.op == ST_RELVORT || prm.op == ST_DIVERGENCE || prm.op == ST_ABSVORT || prm.op == ST_JACOBIAN) {
     bool handled = false;
     const hipError_t e = launch_vortdiv_rows(prm, stream, &handled);
     if (handled)

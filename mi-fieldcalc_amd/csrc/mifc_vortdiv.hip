@@ -150,7 +150,9 @@ __device__ __forceinline__ void decode_block(const RowsParams& P, int seq, int& 
   }
 }
 
-template <bool CHECK, bool WANT_V, bool WANT_D, bool ABSV, int D, bool NT, int V>
+// JAC: the same data pattern (W/E/N/S neighbours of two fields) computes jacobian(field1, field2)
+// (FieldCalculations.cc:2424-2460) into the first output instead.
+template <bool CHECK, bool WANT_V, bool WANT_D, bool ABSV, int D, bool NT, int V, bool JAC = false>
 __global__ __launch_bounds__(256) void vortdiv_rows_kernel(const RowsParams P)
 {
   constexpr int W = D + 3;    // ring slots: rows r-2 (being refilled), r-1, r, r+1, r+2 .. r+D
@@ -330,13 +332,23 @@ __global__ __launch_bounds__(256) void vortdiv_rows_kernel(const RowsParams P)
           const float vw = vc[k], ve = vc[k + 2], uw = uc[k], ue = uc[k + 2];
           const float ua = rp.u[q][k], ub = rn.u[q][k], va = rp.v[q][k], vb = rn.v[q][k]; // rows j-1 / j+1 in walk order
           bool ok = true;
-          if (CHECK)
+          if (CHECK && !JAC)
             ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(ua, undef) && is_def(ub, undef)); // :1861, :1927
+          if (CHECK && JAC) // :2443-2444: all eight neighbours
+            ok = all || (is_def(uw, undef) && is_def(ue, undef) && is_def(ua, undef) && is_def(ub, undef) && is_def(vw, undef) && is_def(ve, undef) &&
+                         is_def(va, undef) && is_def(vb, undef));
           const float dudy = up ? (ua - ub) : (ub - ua); // u[i+nx] - u[i-nx]
           const float dvdy = up ? (va - vb) : (vb - va);
           zv[k] = 0.f;
           zd[k] = 0.f;
-          if (WANT_V)
+          if (JAC) { // :2445-2449: four float-rounded partials, float combination
+            const double hx = 0.5 * (double)xm4[k], hy = 0.5 * (double)ym4[k];
+            const float df1dx = (float)(hx * (double)(ue - uw));
+            const float df1dy = (float)(hy * (double)dudy);
+            const float df2dx = (float)(hx * (double)(ve - vw));
+            const float df2dy = (float)(hy * (double)dvdy);
+            zv[k] = ok ? (df1dx * df2dy - df1dy * df2dx) : undef;
+          } else if (WANT_V)
             zv[k] = ok ? (ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, dudy, fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, dudy)) : undef;
           if (WANT_D)
             zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, dvdy) : undef;
@@ -542,7 +554,7 @@ int tune_value(const char* s, const char* key, int dflt)
 
 Tuning current_tuning(int nx)
 {
-  Tuning t = {0, 6, 1, 1, 2, 1, 1, 4, 1, 0, 0, 0, 0}; // R=6: 120 bands of 6 rows tile the 718 computed rows of a 720-row field almost exactly and measured ~1 % ahead of R=8
+  Tuning t = {0, 8, 1, 1, 2, 1, 1, 4, 1, 0, 0, 0, 0}; // R = 6 runs within 1 % of R = 8 but re-reads more halo rows (HBM traffic 1.14x vs 1.08x of the minimum)
   // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,V=2,ORDER=1,XCD=1,WPB=8" -- used by the sweep tool and the tests
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     t.K = tune_value(s, "K", t.K);
@@ -596,6 +608,10 @@ void launch_d(const RowsParams& rp, const Tuning& t, int grid, hipStream_t strea
     launch_v<CHECK, WV, WD, ABSV, 1, false>(rp, t, grid, stream);
     return;
   }
+  if (!(WV && WD)) { // single-output forms: default depth only (the depth sweep is about the fused kernel)
+    launch_v<CHECK, WV, WD, ABSV, 1, true>(rp, t, grid, stream);
+    return;
+  }
   switch (t.D) {
   case 0:
     launch_v<CHECK, WV, WD, ABSV, 0, true>(rp, t, grid, stream);
@@ -610,6 +626,16 @@ void launch_d(const RowsParams& rp, const Tuning& t, int grid, hipStream_t strea
     launch_v<CHECK, WV, WD, ABSV, 3, true>(rp, t, grid, stream);
     break;
   }
+}
+
+template <bool CHECK>
+void launch_jacobian(const RowsParams& rp, const Tuning& t, int grid, hipStream_t stream)
+{
+  const size_t lds = (size_t)rp.R * 1024 * t.V * 2;
+  if (t.V == 2)
+    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, true, false, false, 1, true, 2, true>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
+  else
+    hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, true, false, false, 1, true, 1, true>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
 }
 
 template <bool CHECK>
@@ -651,6 +677,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     rv = prm.out0;
     if (!prm.fcoriolis || !aligned16(prm.fcoriolis))
       return hipSuccess;
+  } else if (prm.op == ST_JACOBIAN) {
+    rv = prm.out0;
   } else {
     return hipSuccess;
   }
@@ -721,7 +749,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   int grid = rp.per_xcd * 8;
 
   *handled = true;
-  if (t.K == 1 && !rp.fc) { // one-shot form: units are (level, block of 4 rows, 256-column segment)
+  if (t.K == 1 && !rp.fc && prm.op != ST_JACOBIAN) { // one-shot form: units are (level, block of 4 rows, 256-column segment)
     rp.uB = (rp.hi - rp.lo + 3) / 4;
     rp.uW = (nx + 255) / 256;
     const long units = (long)prm.nlev * rp.uB * rp.uW;
@@ -754,6 +782,15 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       }
       return hipGetLastError();
     }
+  }
+  if (prm.op == ST_JACOBIAN) {
+    if (t.V == 3)
+      t.V = 2;
+    if (prm.every_level_all_defined)
+      launch_jacobian<false>(rp, t, grid, stream);
+    else
+      launch_jacobian<true>(rp, t, grid, stream);
+    return hipGetLastError();
   }
   if (prm.every_level_all_defined)
     launch_outputs<false>(rp, t, grid, stream);

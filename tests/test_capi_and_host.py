@@ -98,6 +98,32 @@ int main()
                  fieldcalc::is_defined(true, UNDEF, UNDEF) && fieldcalc::is_defined(1.f, UNDEF);
   std::printf("%d %d %d %d %g %g v%d %d\n", ok1, ok2, ok3, d, (double)absval(3.f, 4.f), (double)constants::t0,
               MI_FIELDCALC_VERSION_CURRENT_INT, (int)checkDefined((size_t)0, (size_t)5));
+  // the rest of the catalogue and the ensemble reductions: std::vector signatures included
+  ValuesDefined f3 = ALL_DEFINED;
+  const bool ok4 = fieldcalc::fieldOPERfield(1, nx, ny, u.data(), v.data(), out.data(), f3, UNDEF);
+  const float sum1 = out[7];
+  std::vector<float*> members;
+  members.push_back(u.data());
+  members.push_back(v.data());
+  members.push_back(u.data());
+  ValuesDefined f4 = SOME_DEFINED;
+  const bool ok5 = fieldcalc::sumFields(nx, ny, members, out.data(), f4, UNDEF);
+  const float sum2 = out[7];
+  std::vector<ValuesDefined> fin(3, ALL_DEFINED);
+  ValuesDefined f5 = SOME_DEFINED;
+  const bool ok6 = fieldcalc::meanValue(nx, ny, members, fin, out.data(), f5, UNDEF);
+  const float mean = out[7];
+  std::vector<float> limits;
+  limits.push_back(0.f);
+  limits.push_back(3.5f);
+  limits.push_back(7.f);
+  limits.push_back(10.f);
+  ValuesDefined f6 = ALL_DEFINED;
+  const bool ok7 = fieldcalc::values2classes(nx, ny, v.data(), out.data(), limits, f6, UNDEF);
+  const float cls = out[7];
+  ValuesDefined f7 = ALL_DEFINED;
+  fieldcalc::maxvalueFieldConst(nx, ny, u.data(), 3.5f, out.data(), f7, UNDEF); // a void function of the reference
+  std::printf("%d %g %d %g %d %g %d %g %g\n", ok4, (double)sum1, ok5, (double)sum2, ok6, (double)mean, ok7, (double)cls, (double)out[7]);
   return 0;
 }
 """
@@ -123,6 +149,11 @@ def test_cxx_header_is_source_compatible(built, tmp_path):
     assert fields[0] == ("1" if have_gpu else "0") and fields[1] == fields[0]
     assert fields[2] == "0" and fields[3] == "1" and fields[4] == "5" and fields[5].startswith("273.1")
     assert fields[6] == "v1009" and fields[7] == "0"
+    more = res.stdout.splitlines()[1].split()
+    if have_gpu:  # u = 3, v = 4 everywhere
+        assert more == ["1", "7", "1", "10", "1", "3.33333", "1", "1", "3.5"], more
+    else:
+        assert more[0] == more[2] == more[4] == more[6] == "0"
 
 
 def test_shard_range_partitions_exactly():

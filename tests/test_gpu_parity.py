@@ -108,6 +108,50 @@ def test_python_surface_matches_reference_module(gpu_ctx, oracle):
         pyfc.vesselIcingMincog(*([t] * 11), 5.0, 0.5, 1.0, 4.0, 1, 1e35)
 
 
+def test_cxx_api_runs_on_the_gpu(gpu_ctx, tmp_path):
+    """The source-compatible C++ API (unchanged caller code, host pointers, std::vector
+    signatures) with a device present: operators return true and the values are right."""
+    import test_capi_and_host as host_tests
+
+    host_tests.test_cxx_header_is_source_compatible(host_tests.LIB, tmp_path)
+
+
+def test_concurrent_callers_with_their_own_contexts(oracle):
+    """The reference is re-entrant and its Python binding releases the GIL
+    (python/py_mi_fieldcalc.cc:75): several threads call at once.  One context per
+    thread; every thread checks its own results against the oracle."""
+    import threading
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny = 516, 70
+    xm, ym, fcor = synth.grid_maps(nx, ny)
+    errors = []
+
+    def worker(k):
+        try:
+            ctx = fc.Context(0)
+            for it in range(6):
+                u, v = synth.wind(nx, ny, 100 * k + it)
+                u = synth.sprinkle_undef(u, k + it, 0.02)
+                for op, args in (("relvort", [u, v, xm, ym]), ("absvort", [u, v, xm, ym, fcor]), ("vectorabs", [u, v])):
+                    ok, expect, flag_e = oracle.call(op, nx, ny, *args, fdefined=SOME)
+                    out, flag = getattr(ctx, op)(*args, fdefined=SOME)
+                    if not (ok and flag == flag_e and cases.same_bits(out, expect, nan_payload=False)):
+                        errors.append((k, it, op))
+            ctx.close()
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_ensemble_reductions(gpu_ctx, oracle):
     """sum / mean / stddev / extreme / probability over members, bit-exact
     (the members are reduced in index order, like the reference's inner loop)."""
