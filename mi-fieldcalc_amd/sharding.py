@@ -14,6 +14,13 @@ ROCm, "gloo" in the CPU tests):
   and direction over xGMI), then every rank runs the slab kernel
   (mifc_vortdiv_slab_enqueue); the undefined counts are summed with one
   8-byte all-reduce to classify the whole field.
+
+* reductions over ensemble members when the MEMBERS are what
+  is sharded -> ``reshard_members_to_rows`` moves the ensemble once so that
+  every rank holds all members of its own row slab (grouped send/recv), the
+  per-cell reduction then runs locally in member order (bit-identical to the
+  unsharded result); ``gather_member_flags`` / ``combine_slab_flags`` carry the
+  ValuesDefined flags across.
 """
 
 
@@ -50,6 +57,87 @@ def exchange_halo_rows(fields_with_halo, rank, world_size, group=None):
         return
     for req in dist.batch_isend_irecv(ops):
         req.wait()
+
+
+def _collective_device(group=None):
+    """Small bookkeeping tensors live where the backend wants them (RCCL: on the GPU)."""
+    import torch
+    import torch.distributed as dist
+
+    if str(dist.get_backend(group)).lower() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def reshard_members_to_rows(local_members, rank, world_size, group=None):
+    """Ensemble reductions (sumFields, meanValue, stddevValue, extremeValue,
+    probability) reduce over the members of every cell IN MEMBER ORDER; that order is
+    what makes the float results identical to the reference's.  When the members
+    are sharded over ranks (``shard_range`` blocks), each rank therefore first
+    collects, for its own row slab, the rows of ALL members -- one all-to-all of
+    the ensemble, done here with grouped send/recv (RCCL over xGMI; gloo in the CPU
+    tests) -- and then reduces locally without any further exchange.
+
+    local_members: tensor [m_local, ny, nx], this rank's contiguous block of members.
+    Returns a tensor [m_total, rows_local, nx] in global member order, where
+    rows_local = slab_rows(ny, world_size, rank)[1]."""
+    import torch
+    import torch.distributed as dist
+
+    m_local, ny, nx = local_members.shape
+    counts = torch.zeros(world_size, dtype=torch.int64, device=local_members.device)
+    counts[rank] = m_local
+    dist.all_reduce(counts, group=group)
+    counts = [int(c) for c in counts.tolist()]
+    j0, rows = slab_rows(ny, world_size, rank)
+    parts = [None] * world_size
+    send_keep = []
+    ops = []
+    for peer in range(world_size):
+        if peer == rank:
+            parts[peer] = local_members[:, j0:j0 + rows, :]
+            continue
+        p0, prow = slab_rows(ny, world_size, peer)
+        if m_local > 0 and prow > 0:
+            out = local_members[:, p0:p0 + prow, :].contiguous()
+            send_keep.append(out)
+            ops.append(dist.P2POp(dist.isend, out, peer, group))
+        buf = torch.empty((counts[peer], rows, nx), dtype=local_members.dtype, device=local_members.device)
+        parts[peer] = buf
+        if counts[peer] > 0 and rows > 0:
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return torch.cat(parts, dim=0).contiguous()
+
+
+def gather_member_flags(local_flags, rank, world_size, group=None):
+    """Per-member ValuesDefined flags of all ranks, in global member order."""
+    import torch
+    import torch.distributed as dist
+
+    dev = _collective_device(group)
+    n = torch.zeros(world_size, dtype=torch.int64, device=dev)
+    n[rank] = len(local_flags)
+    dist.all_reduce(n, group=group)
+    width = int(n.max().item())
+    mine = torch.full((width,), -1, dtype=torch.int64, device=dev)
+    mine[:len(local_flags)] = torch.tensor([int(f) for f in local_flags], dtype=torch.int64, device=dev)
+    gathered = [torch.empty(width, dtype=torch.int64, device=dev) for _ in range(world_size)]
+    dist.all_gather(gathered, mine, group=group)
+    return [int(x) for r, g in enumerate(gathered) for x in g[:int(n[r].item())].tolist()]
+
+
+def combine_slab_flags(local_flag, group=None):
+    """ValuesDefined of the whole field from the flags of its row slabs (every
+    slab non-empty): ALL if all are ALL, NONE if all are NONE, else SOME."""
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([1 if local_flag == 0 else 0, 1 if local_flag == 1 else 0], dtype=torch.int64, device=_collective_device(group))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return 0 if int(t[0]) == 1 else (1 if int(t[1]) == 1 else 2)
 
 
 def global_undefined_count(local_count_tensor, group=None):

@@ -100,3 +100,56 @@ def test_halo_exchange_and_sharding_gloo(world, tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, 48, 23, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+def _ensemble_worker(rank, world, port, nx, ny, nmem, result_dir):
+    """Members sharded over ranks -> every rank collects all members of its row slab
+    (sharding.reshard_members_to_rows) and reduces locally, in member order.  The
+    reduction itself is a HIP kernel and cannot run here; the oracle reduces the
+    resharded slab and the result must equal the whole-field reference bit for bit."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+
+    import mi_fieldcalc_amd.synth as synth
+    from cpulib import CpuLib
+    from mi_fieldcalc_amd.sharding import combine_slab_flags, gather_member_flags, reshard_members_to_rows, shard_range, slab_rows
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        oracle = CpuLib("oracle")
+        members = [synth.uniform((ny, nx), 900 + k, -5.0, 30.0).astype(np.float32) for k in range(nmem)]
+        members[1] = synth.sprinkle_undef(members[1], 3, 0.2)
+        flags = [2 if k == 1 else 0 for k in range(nmem)]
+        ok, mean_g, flag_g = oracle.call("meanValue", nx, ny, members, flags, fdefined=2)
+        ok, std_g, _ = oracle.call("stddevValue", nx, ny, members, flags, fdefined=2)
+        m0, m1 = shard_range(nmem, world, rank)
+        local = torch.from_numpy(np.stack(members[m0:m1])) if m1 > m0 else torch.empty((0, ny, nx))
+        slab = reshard_members_to_rows(local, rank, world)
+        j0, rows = slab_rows(ny, world, rank)
+        assert tuple(slab.shape) == (nmem, rows, nx)
+        for k in range(nmem):
+            assert np.array_equal(slab[k].numpy().view(np.uint32), members[k][j0:j0 + rows].view(np.uint32))
+        all_flags = gather_member_flags(flags[m0:m1], rank, world)
+        assert all_flags == flags
+        slab_members = [np.ascontiguousarray(slab[k].numpy()) for k in range(nmem)]
+        ok, mean_l, flag_l = oracle.call("meanValue", nx, rows, slab_members, all_flags, fdefined=2)
+        ok, std_l, _ = oracle.call("stddevValue", nx, rows, slab_members, all_flags, fdefined=2)
+        assert np.array_equal(mean_l.view(np.uint32), mean_g[j0:j0 + rows].view(np.uint32))
+        assert np.array_equal(std_l.view(np.uint32), std_g[j0:j0 + rows].view(np.uint32))
+        assert combine_slab_flags(flag_l) == flag_g
+        open(os.path.join(result_dir, "ens%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nmem", [(2, 5), (3, 7), (3, 2)])
+def test_member_sharded_ensemble_reshard_gloo(world, nmem, tmp_path):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_ensemble_worker, args=(world, port, 40, 17, nmem, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ens%d" % r)) for r in range(world))
