@@ -29,6 +29,10 @@ typedef unsigned long long u64;
 #define MIFC_K_RHMIN ((float)0.02)
 #define MIFC_K_RHMAX 1.0f
 #define MIFC_N_EWT 41
+// LDS copy of the table: the 41 values, then 26 start indices for the inverse lookup (one per
+// binary exponent of the argument, see Ewt::inverse)
+#define MIFC_EWT_FIRST_N 26
+#define MIFC_EWT_LDS (MIFC_N_EWT + MIFC_EWT_FIRST_N)
 
 // FieldCalculations.h:42-45
 __device__ __forceinline__ bool is_def(float x, float undef)
@@ -53,8 +57,12 @@ __device__ __forceinline__ void ewt_table_init(float* lds_tab)
       (float)2.8627,  (float)4.2148,  (float)6.1078,  (float)8.7192,  (float)12.272,  (float)17.044,  (float)23.373,  (float)31.671, (float)42.430,
       (float)56.236,  (float)73.777,  (float)95.855,  (float)123.40,  (float)157.46,  (float)199.26,  (float)250.16,  (float)311.69, (float)385.56,
       (float)473.67,  (float)578.09,  (float)701.13,  (float)845.28,  (float)1013.25};
+  // first[b]: largest k with ewt[k] <= 2^(b-15) (0 if none), b = 0..25; consecutive entries differ by at most 4
+  const int first[MIFC_EWT_FIRST_N] = {0, 0, 1, 2, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 15, 17, 18, 20, 22, 25, 27, 30, 33, 36, 40};
   for (int k = threadIdx.x; k < MIFC_N_EWT; k += blockDim.x)
     lds_tab[k] = init[k];
+  for (int k = threadIdx.x; k < MIFC_EWT_FIRST_N; k += blockDim.x)
+    lds_tab[MIFC_N_EWT + k] = __int_as_float(first[k]);
   __syncthreads();
 }
 
@@ -71,11 +79,36 @@ struct Ewt
   }
   __device__ __forceinline__ bool ok() const { return l >= 0 && l < MIFC_N_EWT - 1; }
   __device__ __forceinline__ float value(const float* tab) const { return tab[l] + (tab[l + 1] - tab[l]) * (x - (float)l); }
+  // MetConstants.cc:37-45: `ll = l; while (ll > 0 && ll < 40 && ewt[ll] > et) ll--;` -- a walk
+  // down the (strictly increasing) table whose length differs from lane to lane.  The same ll
+  // without a loop: the walk stops at the largest k <= l for which !(ewt[k] > et) holds, or at
+  // 0.  That k is found from the binary exponent of et (first[]: where the table crosses each
+  // power of two; the table crosses at most 4 entries per octave) plus four independent
+  // compares.  NaN never satisfies `>`: the walk does not move (ll = l).
   __device__ __forceinline__ float inverse(const float* tab, float et) const
   {
+#ifdef MIFC_EWT_INVERSE_WALK
     int ll = l;
     while (ll > 0 && ll < MIFC_N_EWT - 1 && tab[ll] > et)
       ll--;
+#else
+    const int bits = __float_as_int(et);
+    const int e = ((bits >> 23) & 0xff) - 127;
+    int b = e < -15 ? 0 : (e > 10 ? 25 : e + 15);
+    if (bits < 0)
+      b = 0; // negative: no entry satisfies the predicate, the compares below all fail
+    const int m0 = __float_as_int(tab[MIFC_N_EWT + b]);
+    int m = m0;
+#pragma unroll
+    for (int j = 1; j <= 4; ++j) {
+      const int k = m0 + j;
+      const float tk = tab[k < MIFC_N_EWT ? k : MIFC_N_EWT - 1];
+      m += (k < MIFC_N_EWT && !(tk > et)) ? 1 : 0;
+    }
+    if (et != et)
+      m = MIFC_N_EWT - 1;
+    const int ll = m < l ? m : l;
+#endif
     const float r = (et - tab[ll]) / (tab[ll + 1] - tab[ll]);
     return (float)(-100. + (double)((float)ll + r) * 5.);
   }

@@ -153,7 +153,7 @@ __host__ __device__ inline bool ewise_needs_pow(const EwiseParams& P)
 template <bool VEC4>
 __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
 {
-  __shared__ float s_ewt[MIFC_N_EWT];
+  __shared__ float s_ewt[MIFC_EWT_LDS];
   __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
   // the lookup tables cost a few hundred cycles per workgroup: staged only
   // for the operator variants that read them (wave-uniform conditions)
@@ -277,7 +277,7 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
 template <bool CHECK>
 __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams P)
 {
-  __shared__ float s_ewt[MIFC_N_EWT];
+  __shared__ float s_ewt[MIFC_EWT_LDS];
   __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
   ewt_table_init(s_ewt);
   const PowTables PT = pow_tables_init(s_pow);

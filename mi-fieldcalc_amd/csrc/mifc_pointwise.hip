@@ -455,7 +455,7 @@ template <int OP, bool VEC4>
 __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
 {
   constexpr int NIN = PwTraits<OP>::nin;
-  __shared__ float s_ewt[PwTraits<OP>::ewt ? MIFC_N_EWT : 1];
+  __shared__ float s_ewt[PwTraits<OP>::ewt ? MIFC_EWT_LDS : 1];
   __shared__ double s_pow[PwTraits<OP>::pow ? (2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N) : 1];
   if (PwTraits<OP>::ewt)
     ewt_table_init(s_ewt);
