@@ -8,6 +8,8 @@
 #include "mifc_device.h"
 #include "mifc_kernels.h"
 
+#include <cstdlib>
+
 namespace mifc {
 
 // outputs are written once and never re-read by this library: nontemporal store
@@ -28,13 +30,14 @@ namespace {
 // defined (r holds the value); false => cell := undef and is counted.
 // `keep` is set for the one case where the reference leaves a defined cell
 // unwritten (hleveltemp with compute outside 1..5, FieldCalculations.cc:1080-1090).
+template <int OP>
 __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* tab, const PowTables& PT, int cell, float a, float b, float c, float& r,
                                             bool& keep)
 {
   const bool all = P.all_defined != 0;
   const float undef = P.undef;
   keep = false;
-  switch (P.op) {
+  switch (OP) { // compile-time: every operator is its own kernel instantiation
   case EW_VECTORABS: { // :1831-1837
     if (!(all || (is_def(a, undef) && is_def(b, undef))))
       return false;
@@ -132,7 +135,7 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
       fcor = P.fcormin;
     else if (fcor <= 0.f && fcor > -P.fcormin)
       fcor = -P.fcormin;
-    if (P.op == EW_MOMENTUM_X)
+    if (OP == EW_MOMENTUM_X)
       r = (float)(cell % P.nx) + a * b / fcor;
     else
       r = (float)(cell / P.nx) - a * b / fcor;
@@ -150,7 +153,7 @@ __host__ __device__ inline bool ewise_needs_pow(const EwiseParams& P)
   return P.psrc != PS_SCALAR && (P.op == EW_TEMP || (P.op == EW_HUM && P.from_theta));
 }
 
-template <bool VEC4>
+template <int OP, bool VEC4>
 __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
 {
   __shared__ float s_ewt[MIFC_EWT_LDS];
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
 
   const bool use1 = P.in1 != nullptr;
   const bool use2 = P.in2 != nullptr;
-  const bool may_keep = (P.op == EW_TEMP) && (P.compute < 1 || P.compute > 5);
+  const bool may_keep = (OP == EW_TEMP) && (P.compute < 1 || P.compute > 5);
   unsigned int bad = 0;
 
   if (VEC4) {
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
       for (int k = 0; k < 4; ++k) {
         float r = 0.f;
         bool keep;
-        if (ewise_point(P, s_ewt, PT, q * 4 + k, av[k], bv[k], cv[k], r, keep)) {
+        if (ewise_point<OP>(P, s_ewt, PT, q * 4 + k, av[k], bv[k], cv[k], r, keep)) {
           if (!keep)
             ov[k] = r;
         } else {
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
       const float c = use2 ? P.in2[i] : 0.f;
       float r = 0.f;
       bool keep;
-      if (ewise_point(P, s_ewt, PT, i + P.cell0, a, b, c, r, keep)) {
+      if (ewise_point<OP>(P, s_ewt, PT, i + P.cell0, a, b, c, r, keep)) {
         if (!keep)
           P.out[i] = r;
       } else {
@@ -235,19 +238,25 @@ inline int grid_for(int work_items, int block, int max_blocks)
 
 } // namespace
 
-hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
+namespace {
+
+template <int OP>
+hipError_t launch_ewise_op(const EwiseParams& prm, hipStream_t stream)
 {
-  if (prm.n <= 0)
-    return hipSuccess;
   const bool vec_ok = aligned16(prm.in0) && aligned16(prm.out) && (!prm.in1 || aligned16(prm.in1)) && (!prm.in2 || aligned16(prm.in2)) && prm.n >= 4;
   const int block = 256;
   if (vec_ok) {
     const int n4 = prm.n >> 2;
     // Table-free variants: one float4 per lane, workgroups in address order (the
     // streaming shape that measured fastest on MI355X).  Variants that stage
-    // lookup tables per workgroup amortise that over a grid-stride loop.
+    // lookup tables per workgroup amortise that over a grid-stride loop
+    // (MIFC_EWISE_MAX_BLOCKS overrides the cap, for A/B measurements).
     const bool tables = ewise_needs_ewt(prm) || ewise_needs_pow(prm);
-    hipLaunchKernelGGL(ewise_kernel<true>, dim3(grid_for(n4, block, tables ? 256 * 16 : 0x7fffffff)), dim3(block), 0, stream, prm);
+    int cap = tables ? 256 * 16 : 0x7fffffff;
+    if (const char* e = std::getenv("MIFC_EWISE_MAX_BLOCKS"))
+      if (std::atoi(e) > 0)
+        cap = std::atoi(e);
+    hipLaunchKernelGGL((ewise_kernel<OP, true>), dim3(grid_for(n4, block, cap)), dim3(block), 0, stream, prm);
     const int tail = prm.n - n4 * 4;
     if (tail > 0) {
       EwiseParams t = prm;
@@ -257,12 +266,38 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
       t.in2 = prm.in2 ? prm.in2 + n4 * 4 : nullptr;
       t.out = prm.out + n4 * 4;
       t.cell0 = n4 * 4;
-      hipLaunchKernelGGL(ewise_kernel<false>, dim3(1), dim3(64), 0, stream, t);
+      hipLaunchKernelGGL((ewise_kernel<OP, false>), dim3(1), dim3(64), 0, stream, t);
     }
   } else {
-    hipLaunchKernelGGL(ewise_kernel<false>, dim3(grid_for(prm.n, block, 256 * 16)), dim3(block), 0, stream, prm);
+    hipLaunchKernelGGL((ewise_kernel<OP, false>), dim3(grid_for(prm.n, block, 256 * 16)), dim3(block), 0, stream, prm);
   }
   return hipGetLastError();
+}
+
+} // namespace
+
+hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
+{
+  if (prm.n <= 0)
+    return hipSuccess;
+  switch (prm.op) {
+  case EW_VECTORABS:
+    return launch_ewise_op<EW_VECTORABS>(prm, stream);
+  case EW_TEMP:
+    return launch_ewise_op<EW_TEMP>(prm, stream);
+  case EW_HUM:
+    return launch_ewise_op<EW_HUM>(prm, stream);
+  case EW_CVHUM_TD:
+    return launch_ewise_op<EW_CVHUM_TD>(prm, stream);
+  case EW_CVHUM_RH:
+    return launch_ewise_op<EW_CVHUM_RH>(prm, stream);
+  case EW_MOMENTUM_X:
+    return launch_ewise_op<EW_MOMENTUM_X>(prm, stream);
+  case EW_MOMENTUM_Y:
+    return launch_ewise_op<EW_MOMENTUM_Y>(prm, stream);
+  default:
+    return hipErrorInvalidValue;
+  }
 }
 
 // ----------------------------------------------------------------------------

@@ -455,15 +455,12 @@ template <int OP, bool VEC4>
 __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
 {
   constexpr int NIN = PwTraits<OP>::nin;
+  constexpr int NV = NIN > 0 ? NIN : 1;
   __shared__ float s_ewt[PwTraits<OP>::ewt ? MIFC_EWT_LDS : 1];
   __shared__ double s_pow[PwTraits<OP>::pow ? (2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N) : 1];
-  if (PwTraits<OP>::ewt)
-    ewt_table_init(s_ewt);
   PowTables PT;
   PT.logt = s_pow;
   PT.expt = s_pow;
-  if (PwTraits<OP>::pow)
-    PT = pow_tables_init(s_pow);
 
   const bool all = P.all_defined != 0;
   const float undef = P.undef;
@@ -471,22 +468,28 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
 
   if (VEC4) {
     const int n4 = P.n >> 2;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += gridDim.x * blockDim.x) {
-      float4 v[NIN > 0 ? NIN : 1];
+    int q = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 v[NV];
+    float4 old = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the loads of the (first) cells go out before the lookup tables are staged
+    auto fetch = [&](int qq) {
 #pragma unroll
       for (int k = 0; k < NIN; ++k)
-        v[k] = reinterpret_cast<const float4*>(P.in[k])[q];
-      float o[4] = {0.f, 0.f, 0.f, 0.f};
-      if (P.may_keep) {
-        const float4 old = reinterpret_cast<const float4*>(P.out)[q];
-        o[0] = old.x;
-        o[1] = old.y;
-        o[2] = old.z;
-        o[3] = old.w;
-      }
+        v[k] = reinterpret_cast<const float4*>(P.in[k])[qq];
+      if (P.may_keep)
+        old = reinterpret_cast<const float4*>(P.out)[qq];
+    };
+    if (q < n4)
+      fetch(q);
+    if (PwTraits<OP>::ewt)
+      ewt_table_init(s_ewt);
+    if (PwTraits<OP>::pow)
+      PT = pow_tables_init(s_pow);
+    while (q < n4) {
+      float o[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        float x[NIN > 0 ? NIN : 1];
+        float x[NV];
         bool def = true;
 #pragma unroll
         for (int k = 0; k < NIN; ++k) {
@@ -506,10 +509,17 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
         bad += (st == PW_UNDEF || st == PW_SKIP) ? 1u : 0u;
       }
       pw_store4(P.out + (size_t)q * 4, o);
+      q += gridDim.x * blockDim.x;
+      if (q < n4)
+        fetch(q);
     }
   } else {
+    if (PwTraits<OP>::ewt)
+      ewt_table_init(s_ewt);
+    if (PwTraits<OP>::pow)
+      PT = pow_tables_init(s_pow);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x) {
-      float x[NIN > 0 ? NIN : 1];
+      float x[NV];
       bool def = true;
 #pragma unroll
       for (int k = 0; k < NIN; ++k) {
@@ -546,8 +556,7 @@ hipError_t launch_pw(const PwParams& prm, hipStream_t stream)
   for (int k = 0; k < NIN; ++k)
     vec_ok = vec_ok && aligned16(prm.in[k]);
   const int block = 256;
-  const bool tables = PwTraits<OP>::ewt || PwTraits<OP>::pow;
-  const int cap = tables ? 256 * 16 : 0x7fffffff; // table staging is amortised over a grid-stride loop
+  const int cap = 0x7fffffff; // one float4 per lane: table staging (where an operator needs it) runs under the load latency
   if (vec_ok) {
     const int n4 = prm.n >> 2;
     int g = (n4 + block - 1) / block;

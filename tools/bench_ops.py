@@ -9,6 +9,7 @@ on one core for the same operator.
 """
 import json
 import os
+import re
 import sys
 import time
 
@@ -82,7 +83,11 @@ def main():
 
     rows = []
 
+    only = os.environ.get("BENCH_OPS_ONLY")  # regular expression on the operator name
+
     def add(name, bytes_per_cell, once_bytes, gpu_fn, cpu_op, cpu_args):
+        if only and not re.search(only, name):
+            return
         ms = gpu_time(gpu_fn)
         alg = cells * bytes_per_cell + once_bytes
         cr = cpu_rate(cpu, cpu_op, cpu_args)
@@ -154,6 +159,8 @@ def main():
     o1 = out[0]
 
     def add_ens(name, gpu_fn, cpu_op, cpu_args):
+        if only and not re.search(only, name):
+            return
         ms = gpu_time(gpu_fn)
         alg = n * 4 * (nm + 1)
         t0 = time.perf_counter()
