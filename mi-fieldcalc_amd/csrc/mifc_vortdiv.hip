@@ -153,7 +153,7 @@ __device__ __forceinline__ void decode_block(const RowsParams& P, int seq, int& 
 // JAC: the same data pattern (W/E/N/S neighbours of two fields) computes jacobian(field1, field2)
 // (FieldCalculations.cc:2424-2460) into the first output instead.
 template <bool CHECK, bool WANT_V, bool WANT_D, bool ABSV, int D, bool NT, int V, bool JAC = false>
-__global__ __launch_bounds__(256) void vortdiv_rows_kernel(const RowsParams P)
+__global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
 {
   constexpr int W = D + 3;    // ring slots: rows r-2 (being refilled), r-1, r, r+1, r+2 .. r+D
   constexpr int WCOLS = 256 * V; // columns per wave
@@ -554,7 +554,7 @@ int tune_value(const char* s, const char* key, int dflt)
 
 Tuning current_tuning(int nx)
 {
-  Tuning t = {0, 8, 1, 1, 2, 1, 1, 4, 1, 0, 0, 0, 0}; // R = 6 runs within 1 % of R = 8 but re-reads more halo rows (HBM traffic 1.14x vs 1.08x of the minimum)
+  Tuning t = {0, 8, 1, 1, 2, 1, 1, 8, 1, 0, 0, 0, 0}; // R = 6 / WPB = 4 run within 1 % of this but fetch more (halo rows, map factors): HBM traffic 1.13-1.14x vs 1.08x of the minimum
   // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,V=2,ORDER=1,XCD=1,WPB=8" -- used by the sweep tool and the tests
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     t.K = tune_value(s, "K", t.K);
@@ -571,8 +571,8 @@ Tuning current_tuning(int nx)
     t.XS = tune_value(s, "XS", 0);
     t.PADROWS = tune_value(s, "PADROWS", 0);
   }
-  if (t.WPB != 1 && t.WPB != 2 && t.WPB != 4)
-    t.WPB = 4; // the kernel is compiled for workgroups of up to 4 waves (8 and 16 were measured: no gain)
+  if (t.WPB != 1 && t.WPB != 2 && t.WPB != 4 && t.WPB != 8)
+    t.WPB = 4; // the kernel is compiled for workgroups of up to 8 waves
   if (t.V != 1 && t.V != 2 && t.V != 3)
     t.V = 2;
   if (nx <= 256)
@@ -584,8 +584,8 @@ Tuning current_tuning(int nx)
     t.R = rmax;
   if (t.D < 0)
     t.D = 0;
-  if (t.D > 3)
-    t.D = 3;
+  if (t.D > 1)
+    t.D = 1; // deeper rings (2, 3) were measured -- same time, profiles/r01/experiments/sweep_d.txt -- and are not instantiated
   return t;
 }
 
@@ -612,20 +612,10 @@ void launch_d(const RowsParams& rp, const Tuning& t, int grid, hipStream_t strea
     launch_v<CHECK, WV, WD, ABSV, 1, true>(rp, t, grid, stream);
     return;
   }
-  switch (t.D) {
-  case 0:
+  if (t.D == 0)
     launch_v<CHECK, WV, WD, ABSV, 0, true>(rp, t, grid, stream);
-    break;
-  case 1:
+  else
     launch_v<CHECK, WV, WD, ABSV, 1, true>(rp, t, grid, stream);
-    break;
-  case 2:
-    launch_v<CHECK, WV, WD, ABSV, 2, true>(rp, t, grid, stream);
-    break;
-  default:
-    launch_v<CHECK, WV, WD, ABSV, 3, true>(rp, t, grid, stream);
-    break;
-  }
 }
 
 template <bool CHECK>
