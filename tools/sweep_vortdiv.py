@@ -33,7 +33,8 @@ YARD = {
 
 
 def main():
-    tunes = sys.argv[1:] or ["R=32,D=2"]
+    os.environ["MIFC_MEASUREMENT_KNOBS"] = "1"  # XH / XS / PADROWS: timing experiments that give wrong results by design
+    tunes = sys.argv[1:] or ["R=8"]
     dev = torch.device("cuda", 0)
     xm, ym, _ = synth.grid_maps(NX, NY)
     dxm, dym = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
