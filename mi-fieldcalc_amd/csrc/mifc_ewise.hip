@@ -464,6 +464,65 @@ __global__ __launch_bounds__(256) void stream2_kernel(float* __restrict__ d0, fl
     }
   }
 }
+// Variant 3: the same copy as a LOOP kernel with split roles -- waves 0..3 of a
+// workgroup only load (global -> LDS), waves 4..7 only store (LDS -> global).
+// A wave that loads never has a store in its vmcnt queue (the counter is shared
+// and in-order on gfx9), a wave that stores never waits on memory at all.
+// Yardstick for the question "do long-running waves lose bandwidth because
+// their load waits are coupled to their own older stores?".
+__global__ __launch_bounds__(512) void stream2_split_kernel(float* __restrict__ d0, float* __restrict__ d1, const float* __restrict__ s0,
+                                                            const float* __restrict__ s1, size_t n4)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  __shared__ v4f buf[2][2][256]; // [stage][array][position in the 256-float4 tile]
+  const v4f* a = reinterpret_cast<const v4f*>(s0);
+  const v4f* b = reinterpret_cast<const v4f*>(s1);
+  v4f* x = reinterpret_cast<v4f*>(d0);
+  v4f* y = reinterpret_cast<v4f*>(d1);
+  const bool loader = threadIdx.x < 256;
+  const int t = threadIdx.x & 255;
+  const size_t ntiles = (n4 + 255) / 256;
+  const size_t step = gridDim.x;
+  const v4f zero = {0.f, 0.f, 0.f, 0.f};
+  v4f ra0 = zero, rb0 = zero, ra1 = zero, rb1 = zero;
+  auto fetch = [&](size_t tile, v4f& ra, v4f& rb) {
+    const size_t q = tile * 256 + t;
+    if (tile < ntiles && q < n4) {
+      ra = __builtin_nontemporal_load(a + q);
+      rb = __builtin_nontemporal_load(b + q);
+    }
+  };
+  auto put = [&](size_t tile, int stage) {
+    const size_t q = tile * 256 + t;
+    if (q < n4) {
+      __builtin_nontemporal_store(buf[stage][0][t], x + q);
+      __builtin_nontemporal_store(buf[stage][1][t], y + q);
+    }
+  };
+  size_t tile = blockIdx.x;
+  if (loader) { // two tiles in flight per loading wave
+    fetch(tile, ra0, rb0);
+    fetch(tile + step, ra1, rb1);
+  }
+  for (; tile < ntiles; tile += 2 * step) {
+    if (loader) {
+      buf[0][0][t] = ra0;
+      buf[0][1][t] = rb0;
+      fetch(tile + 2 * step, ra0, rb0);
+    }
+    __syncthreads();
+    if (!loader)
+      put(tile, 0);
+    if (loader) {
+      buf[1][0][t] = ra1;
+      buf[1][1][t] = rb1;
+      fetch(tile + 3 * step, ra1, rb1);
+    }
+    __syncthreads();
+    if (!loader && tile + step < ntiles)
+      put(tile + step, 1);
+  }
+}
 } // namespace
 
 hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const float* s0, const float* s1, size_t n_floats, hipStream_t stream)
@@ -474,6 +533,9 @@ hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const f
     blocks = (int)(want > 0x7fffffff ? 0x7fffffff : want);
   }
   switch (variant) {
+  case 3:
+    hipLaunchKernelGGL(stream2_split_kernel, dim3(blocks), dim3(512), 0, stream, d0, d1, s0, s1, n4);
+    break;
   case 0:
     hipLaunchKernelGGL(stream2_kernel<0>, dim3(blocks), dim3(256), 0, stream, d0, d1, s0, s1, n4);
     break;

@@ -1,0 +1,11 @@
+import sys; sys.path.insert(0, '.')
+import torch, mi_fieldcalc_amd as fc
+ctx = fc.Context(0)
+for n in (1440*720*3, 1000*4+ 4*77, 256*4*4096*2 + 4*5):
+    a = torch.randn(n, device='cuda'); b = torch.randn(n, device='cuda')
+    for blocks in (0, 7, 1024):
+        x = torch.zeros_like(a); y = torch.zeros_like(b)
+        assert ctx.bench_stream2(3, blocks, x, y, a, b)
+        torch.cuda.synchronize()
+        assert torch.equal(x, a) and torch.equal(y, b), (n, blocks)
+print("split-role copy correct")

@@ -29,6 +29,10 @@ YARD = {
     "stream2 nt-store, 1 lane/16B": (1, 0),
     "stream2 nt-ld+st, 1 lane/16B": (2, 0),
     "stream2 nt-ld+st, 4096 blk": (2, 4096),
+    "split-role loop copy, 1024 blk": (3, 1024),
+    "split-role loop copy, 2048 blk": (3, 2048),
+    "split-role loop copy, 4096 blk": (3, 4096),
+    "split-role copy, 1 tile pair/blk": (3, 0),
 }
 
 
