@@ -196,6 +196,9 @@ int mifc_snow_in_cm(mifc_ctx* ctx, int nx, int ny, const float* snow_water, cons
 /* values2classes .h:252 / .cc:2462: `values` (class limits, std::vector<float> there) is always a HOST array */
 int mifc_values2classes(mifc_ctx* ctx, int nx, int ny, const float* fvalue, float* fclass, const float* values, int nvalues, int* fdefined,
                         float undef, int memkind);
+/* shapiro2_filter .h:218 / .cc:2076 (second-order Shapiro filter, four sweeps; field == fsmooth allowed,
+ * the flag always becomes ALL_DEFINED) */
+int mifc_shapiro2_filter(mifc_ctx* ctx, int nx, int ny, const float* field, float* fsmooth, int* fdefined, float undef, int memkind);
 /* vesselIcingOverland .h:238 / FieldCalculationsVesselIcing.cc:77; vesselIcingMertins .h:241 / :114
  * (vesselIcingModStall .h:244 and vesselIcingMincog .h:248, the two iterative models, are not built yet) */
 int mifc_vesselIcingOverland(mifc_ctx* ctx, int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v,

@@ -335,6 +335,10 @@ class Context:
         vals = np.ascontiguousarray(values, dtype=np.float32)
         return self._single("mifc_values2classes", [fvalue], [], [out], fdefined, undef, tail=[vals.ctypes.data, int(vals.size)])
 
+    def shapiro2_filter(self, field, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        """Second-order Shapiro filter; pass out=field to smooth in place."""
+        return self._single("mifc_shapiro2_filter", [field], [], [out], fdefined, undef)
+
     def vesselIcingOverland(self, airtemp, seatemp, u, v, sal, aice, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
         return self._single("mifc_vesselIcingOverland", [airtemp, seatemp, u, v, sal, aice], [], [out], fdefined, undef)
 

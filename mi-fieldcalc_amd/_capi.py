@@ -90,6 +90,7 @@ SIGNATURES = {
     "mifc_pressure2FlightLevel": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
     "mifc_snow_in_cm": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_values2classes": ("i", ["ctx", "i", "i", "p", "p", "p", "i", "pi", "f", "i"]),
+    "mifc_shapiro2_filter": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
     "mifc_vesselIcingOverland": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_vesselIcingMertins": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_minvalueFields": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),

@@ -556,6 +556,42 @@ int mifc_values2classes(mifc_ctx* c, int nx, int ny, const float* fvalue, float*
   return run_pointwise(c, nx, ny, pc, fclass, fdefined, memkind);
 }
 
+// ------------------------------------------------------------- second-order Shapiro filter
+// FieldCalculations.cc:2076-2179: four sweeps between the output and a scratch field; `field`
+// and `fsmooth` may be the same array; the flag always becomes ALL_DEFINED (:2176).
+int mifc_shapiro2_filter(mifc_ctx* c, int nx, int ny, const float* field, float* fsmooth, int* fdefined, float undef, int memkind)
+{
+  CTX_OR_FAIL(c);
+  if (nx < 3 || ny < 3 || !field || !fsmooth) // :2093
+    return 0;
+  const size_t n = (size_t)nx * (size_t)ny;
+  if (n > 0x7fffffffu)
+    return 0;
+  bool ok = true;
+  const float* d_in = stage_in(c, 0, field, n, memkind, &ok);
+  float* d_out = stage_out(c, 5, fsmooth, n, memkind, &ok);
+  const bool all = (*fdefined == MIFC_ALL_DEFINED);
+  if (!ok || !ensure_slot(c, 8, n * sizeof(float)) || (!all && !ensure_slot(c, 9, 2 * n)))
+    return 0;
+  if (d_out != d_in)
+    MIFC_HIP(c, hipMemcpyAsync(d_out, d_in, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  mifc::ShapiroParams P;
+  P.nx = nx;
+  P.ny = ny;
+  P.all_defined = all ? 1 : 0;
+  P.undef = undef;
+  P.f1 = d_out;
+  P.f2 = static_cast<float*>(c->slot[8]);
+  P.mask_x = all ? nullptr : static_cast<unsigned char*>(c->slot[9]);
+  P.mask_y = all ? nullptr : static_cast<unsigned char*>(c->slot[9]) + n;
+  MIFC_HIP(c, mifc::launch_shapiro2(P, c->stream));
+  if (!fetch_out(c, 5, fsmooth, n, memkind))
+    return 0;
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  *fdefined = MIFC_ALL_DEFINED;
+  return 1;
+}
+
 // ------------------------------------------------------------- vessel icing (closed-form models)
 static int vessel_icing(mifc_ctx* c, int model, int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v,
                         const float* sal, const float* aice, float* icing, int* fdefined, float undef, int memkind)

@@ -215,6 +215,19 @@ struct StencilParams
 
 hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream);
 
+// second-order Shapiro filter, FieldCalculations.cc:2076 (mifc_shapiro.hip)
+struct ShapiroParams
+{
+  int nx, ny;
+  int all_defined;       // input flag == ALL_DEFINED
+  float undef;
+  float* f1;             // in: the field, out: the smoothed field
+  float* f2;             // scratch, nx*ny floats
+  unsigned char* mask_x; // scratch, nx*ny bytes each (unused when all_defined)
+  unsigned char* mask_y;
+};
+hipError_t launch_shapiro2(const ShapiroParams& prm, hipStream_t stream);
+
 // diagnostic: two-in / two-out streaming copy (bandwidth yardstick)
 hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const float* s0, const float* s1, size_t n_floats, hipStream_t stream);
 

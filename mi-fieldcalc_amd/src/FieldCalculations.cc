@@ -322,6 +322,10 @@ bool values2classes(int nx, int ny, const float* fvalue, float* fclass, const st
   MIFC_FORWARD(mifc_values2classes(context(), nx, ny, fvalue, fclass, values.data(), static_cast<int>(values.size()), f.ptr(), undef, MIFC_MEM_HOST));
 }
 
+bool shapiro2_filter(int nx, int ny, float* field, float* fsmooth, ValuesDefined& fDefined, float undef)
+{
+  MIFC_FORWARD(mifc_shapiro2_filter(context(), nx, ny, field, fsmooth, f.ptr(), undef, MIFC_MEM_HOST));
+}
 bool vesselIcingOverland(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
                          const float* aice, float* icing, ValuesDefined& fDefined, float undef)
 {

@@ -759,6 +759,65 @@ int mifcorc_vesselIcingMertins(int nx, int ny, const float* airtemp, const float
   return vessel_icing_simple(true, nx, ny, airtemp, seatemp, u, v, sal, aice, icing, fdefined, undef);
 }
 
+// ------------------------------------------------------------- second-order Shapiro filter
+// FieldCalculations.cc:2076-2179.  Two sweeps (x then y) with weight +0.25, two with -0.25 --
+// for ALL_DEFINED input.  Otherwise the per-cell weights s1 / s2 are taken ONCE from the
+// unsmoothed field with s = +0.25 (:2141-2145) and reused by both sweeps, i.e. the second
+// sweep smooths again instead of restoring (the assignment s = -0.25 at :2167 never reaches
+// them).  ALL branch: `2. * f` makes the update double; the other branch is float throughout.
+// The flag becomes ALL_DEFINED whatever the content (:2176).  field == fsmooth is allowed.
+int mifcorc_shapiro2_filter(int nx, int ny, const float* field, float* fsmooth, int* fdefined, float undef)
+{
+  const int n = nx * ny;
+  if (nx < 3 || ny < 3)
+    return 0;
+  float* f1 = fsmooth;
+  if (field != fsmooth)
+    for (int i = 0; i < n; ++i)
+      fsmooth[i] = field[i];
+  float* f2 = new float[n];
+  const bool all = *fdefined == ALL_DEFINED;
+  float* s1 = nullptr;
+  float* s2 = nullptr;
+  if (!all) {
+    s1 = new float[n];
+    s2 = new float[n];
+    for (int i = 1; i < n - 1; ++i)
+      s1[i] = (defined1(f1[i - 1], undef) && defined1(f1[i], undef) && defined1(f1[i + 1], undef)) ? 0.25f : 0.f;
+    for (int i = nx; i < n - nx; ++i)
+      s2[i] = (defined1(f1[i - nx], undef) && defined1(f1[i], undef) && defined1(f1[i + nx], undef)) ? 0.25f : 0.f;
+  }
+  float s = 0.25;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 1; i < n - 1; ++i) {
+      if (all)
+        f2[i] = (float)((double)f1[i] + (double)s * ((double)(f1[i - 1] + f1[i + 1]) - 2. * (double)f1[i]));
+      else
+        f2[i] = f1[i] + s1[i] * (f1[i - 1] + f1[i + 1] - 2 * f1[i]);
+    }
+    for (int j = 0; j < ny; ++j) {
+      f2[j * nx] = f1[j * nx];
+      f2[j * nx + nx - 1] = f1[j * nx + nx - 1];
+    }
+    for (int i = nx; i < n - nx; ++i) {
+      if (all)
+        f1[i] = (float)((double)f2[i] + (double)s * ((double)(f2[i - nx] + f2[i + nx]) - 2. * (double)f2[i]));
+      else
+        f1[i] = f2[i] + s2[i] * (f2[i - nx] + f2[i + nx] - 2 * f2[i]);
+    }
+    for (int i = 0; i < nx; ++i) {
+      f1[i] = f2[i];
+      f1[n - nx + i] = f2[n - nx + i];
+    }
+    s = -0.25;
+  }
+  delete[] f2;
+  delete[] s1;
+  delete[] s2;
+  *fdefined = ALL_DEFINED;
+  return 1;
+}
+
 // ------------------------------------------------------------- field algebra (:2501-2669)
 int mifcorc_minvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef)
 {

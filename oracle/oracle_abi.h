@@ -115,6 +115,8 @@ int ORC(vesselIcingOverland)(int nx, int ny, const float* airtemp, const float* 
                              const float* aice, float* icing, int* fdefined, float undef);
 int ORC(vesselIcingMertins)(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
                             const float* aice, float* icing, int* fdefined, float undef);
+/* FieldCalculations.cc:2076 (the reference's `field` is non-const only because it may alias fsmooth) */
+int ORC(shapiro2_filter)(int nx, int ny, const float* field, float* fsmooth, int* fdefined, float undef);
 /* field algebra :2501-2669 (the reference's void functions return 1 here) */
 int ORC(minvalueFields)(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef);
 int ORC(maxvalueFields)(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef);

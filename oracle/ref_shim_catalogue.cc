@@ -156,6 +156,11 @@ int mifcref_vesselIcingMertins(int nx, int ny, const float* airtemp, const float
   SHIM(fc::vesselIcingMertins(nx, ny, airtemp, seatemp, u, v, sal, aice, icing, f.v, undef));
 }
 
+int mifcref_shapiro2_filter(int nx, int ny, const float* field, float* fsmooth, int* fdefined, float undef)
+{
+  SHIM(fc::shapiro2_filter(nx, ny, const_cast<float*>(field), fsmooth, f.v, undef)); // only written when it IS fsmooth
+}
+
 int mifcref_minvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, int* fdefined, float undef)
 {
   Flag f(fdefined);

@@ -59,6 +59,7 @@ def stencil_cases(grids=GRIDS_STENCIL, modes=MODES):
         cases.append(dict(base, op="thermalFrontParameter", args=[z_, xm, ym], label="tfp-" + lab))
         cases.append(dict(base, op="momentumXcoordinate", args=[v_, xm, fc, 2.0e-5], label="momx-" + lab))
         cases.append(dict(base, op="momentumYcoordinate", args=[u_, ym, fc, -3.0e-5], label="momy-" + lab))
+        cases.append(dict(base, op="shapiro2_filter", args=[z_], label="shapiro2-" + lab))
         tq = (250.0 + 0.05 * (z_ - 5500.0)).astype(np.float32) if mode in ("all",) else np.where((z_ == UNDEF) | np.isnan(z_), z_, 250.0 + 0.05 * (z_ - 5500.0)).astype(np.float32)
         for c in (0, 1, 2, 3, 4, 5):
             cases.append(dict(base, op="plevelqvector", args=[z_, tq, xm, ym, fc, 500.0, c], label="qvector%d-%s" % (c, lab)))

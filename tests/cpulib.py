@@ -76,6 +76,7 @@ SIGS = {
     "pressure2FlightLevel": "po",
     "snow_in_cm": "pppo",
     "values2classes": "poV",
+    "shapiro2_filter": "po",
     "vesselIcingOverland": "ppppppo",
     "vesselIcingMertins": "ppppppo",
     "minvalueFields": "ppo",

@@ -108,6 +108,26 @@ def test_python_surface_matches_reference_module(gpu_ctx, oracle):
         pyfc.vesselIcingMincog(*([t] * 11), 5.0, 0.5, 1.0, 4.0, 1, 1e35)
 
 
+@pytest.mark.parametrize("flag", [ALL, SOME])
+def test_shapiro_filter_in_place(gpu_ctx, oracle, flag):
+    """shapiro2_filter allows field == fsmooth (FieldCalculations.cc:2088, :2099): device tensor smoothed in place."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny = 129, 40
+    z = synth.scalar_field(nx, ny, 77)
+    if flag == SOME:
+        z = synth.sprinkle_undef(z, 5, 0.05)
+    expect = z.copy()
+    ok, out_e, flag_e = oracle.call("shapiro2_filter", nx, ny, expect, fdefined=flag, outs=[expect])  # the oracle in place, too
+    assert ok and flag_e == ALL
+    dz = torch.from_numpy(z.copy()).cuda()
+    res, flag_g = gpu_ctx.shapiro2_filter(dz, fdefined=flag, out=dz)
+    assert flag_g == ALL and res.data_ptr() == dz.data_ptr()
+    assert cases.same_bits(dz.cpu().numpy(), expect, nan_payload=False)
+
+
 def test_cxx_api_runs_on_the_gpu(gpu_ctx, tmp_path):
     """The source-compatible C++ API (unchanged caller code, host pointers, std::vector
     signatures) with a device present: operators return true and the values are right."""
