@@ -103,7 +103,15 @@ int run_ensemble(mifc_ctx* c, mifc::EnsembleParams P, int nx, int ny, const floa
   for (int j = 0; j < nfields; ++j)
     if (!fields[j])
       return 0;
-  std::vector<const float*> table((size_t)nfields);
+  std::vector<const float*> table;
+  std::vector<unsigned char> flags;
+  try { // nothing may be thrown across the C ABI
+    table.resize((size_t)nfields);
+    flags.resize((size_t)nfields);
+  } catch (...) {
+    c->err = "out of host memory";
+    return 0;
+  }
   if (memkind == MIFC_MEM_HOST) {
     const size_t stride = (n + 3) & ~size_t(3); // keeps every staged member 16-byte aligned
     if (nfields > 0 && !ensure_slot(c, 0, (size_t)nfields * stride * sizeof(float)))
@@ -122,7 +130,6 @@ int run_ensemble(mifc_ctx* c, mifc::EnsembleParams P, int nx, int ny, const floa
   const size_t table_bytes = ((size_t)nfields * sizeof(float*) + 15) & ~size_t(15);
   if (!ok || !ensure_levels(c, 1) || !ensure_slot(c, 8, table_bytes + (size_t)nfields + 16))
     return 0;
-  std::vector<unsigned char> flags((size_t)nfields);
   if (nfields > 0) {
     MIFC_HIP(c, hipMemcpyAsync(c->slot[8], table.data(), (size_t)nfields * sizeof(float*), hipMemcpyHostToDevice, c->stream));
     if (member_flags) {

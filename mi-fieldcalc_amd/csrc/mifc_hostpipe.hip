@@ -128,7 +128,12 @@ struct HostPipe
 
 HostPipe* hostpipe_create(int device)
 {
-  HostPipe* hp = new (std::nothrow) HostPipe();
+  HostPipe* hp = nullptr;
+  try { // the copy threads are started here; nothing may be thrown across the C ABI above us
+    hp = new (std::nothrow) HostPipe();
+  } catch (...) {
+    return nullptr;
+  }
   if (!hp)
     return nullptr;
   hp->device = device;
@@ -250,7 +255,9 @@ bool hostpipe_run(HostPipe* hp, size_t n, int nlev, int n_in, const float* const
   bool abort = false;
   hipError_t drain_error = hipSuccess;
 
-  std::thread drainer([&] {
+  std::thread drainer;
+  try {
+    drainer = std::thread([&] {
     (void)hipSetDevice(hp->device);
     for (int k = 0; k < nchunks; ++k) {
       {
@@ -280,7 +287,10 @@ bool hostpipe_run(HostPipe* hp, size_t n, int nlev, int n_in, const float* const
       }
       cv.notify_all();
     }
-  });
+    });
+  } catch (...) {
+    return fail("cannot start the drain thread", hipErrorOutOfMemory);
+  }
 
   bool ok = true;
   const char* what = "";
