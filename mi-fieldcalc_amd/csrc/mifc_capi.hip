@@ -1117,7 +1117,7 @@ int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const flo
 
 static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q, const float* ps,
                           const float* alevel, const float* blevel, float* ff, float* rh, float* theta, const int* fdef_wind, const int* fdef_thermo,
-                          float undef, u64* counts_dev, bool* every_all_out)
+                          float undef, u64* counts_dev, bool* every_all_out, mifc::DerivedParams* prepared_only = nullptr)
 {
   if (nlev < 1 || nx * ny <= 0)
     return 0;
@@ -1144,7 +1144,7 @@ static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u,
   P.theta = theta;
   P.undef = undef;
   bool every_all = true;
-  if (nlev <= 8) {
+  if (nlev <= 8 && !prepared_only) {
     // small batch: per-level scalars travel in the kernel arguments
     P.n_inline = 1;
     for (int l = 0; l < nlev; ++l) {
@@ -1184,7 +1184,10 @@ static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u,
   P.every_level_all_defined = every_all ? 1 : 0;
   P.n_undefined = counts_dev;
   MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 3 * sizeof(u64) * (size_t)nlev, c->stream));
-  MIFC_HIP(c, mifc::launch_derived_levels(P, c->stream));
+  if (prepared_only) // the caller launches chunk by chunk (host pipeline)
+    *prepared_only = P;
+  else
+    MIFC_HIP(c, mifc::launch_derived_levels(P, c->stream));
   if (every_all_out)
     *every_all_out = every_all;
   return 1;
@@ -1219,6 +1222,72 @@ int mifc_hlevel_derived_levels(mifc_ctx* c, int nx, int ny, int nlev, const floa
   }
   const size_t n = (size_t)nx * ny, nb = n * (size_t)nlev;
   bool ok = true;
+  if (memkind == MIFC_MEM_HOST && mifc::hostpipe_chunk_levels(n, nlev) > 0 && host_pipeline_enabled()) {
+    // a large batch in host memory: chunks of levels stream through the device, copies
+    // in both directions overlapping the kernels (mifc_hostpipe.h)
+    if (!c->pipe && !(c->pipe = mifc::hostpipe_create(c->device))) {
+      c->err = "host pipeline: cannot create streams";
+      return 0;
+    }
+    const float* dps = (rh || theta) ? stage_in(c, 4, ps, n, memkind, &ok) : nullptr;
+    if (!ok || !ensure_levels(c, (size_t)nlev))
+      return 0;
+    mifc::DerivedParams base;
+    // placeholders mark which fields take part; the chunk launcher substitutes device buffers
+    if (!derived_common(c, nx, ny, nlev, ff ? u : nullptr, ff ? v : nullptr, (rh || theta) ? t : nullptr, rh ? q : nullptr, dps, alevel, blevel, ff, rh,
+                        theta, fdef_wind, fdef_thermo, undef, c->d_counts, nullptr, &base))
+      return 0;
+    MIFC_HIP(c, hipStreamSynchronize(c->stream)); // ps, flags, level coefficients, zeroed counters are in place
+    const float* h_in[4];
+    int slot_u = -1, slot_v = -1, slot_t = -1, slot_q = -1, n_in = 0;
+    if (ff) {
+      slot_u = n_in;
+      h_in[n_in++] = u;
+      slot_v = n_in;
+      h_in[n_in++] = v;
+    }
+    if (rh || theta) {
+      slot_t = n_in;
+      h_in[n_in++] = t;
+    }
+    if (rh) {
+      slot_q = n_in;
+      h_in[n_in++] = q;
+    }
+    float* h_out[3] = {ff, rh, theta};
+    const mifc::ChunkLaunch launch = [&](int l0, int nl, const float* const* d_in, float* const* d_out, hipStream_t stream) {
+      mifc::DerivedParams p = base;
+      p.nlev = nl;
+      p.count_stride = nlev;
+      p.u = slot_u >= 0 ? d_in[slot_u] : nullptr;
+      p.v = slot_v >= 0 ? d_in[slot_v] : nullptr;
+      p.t = slot_t >= 0 ? d_in[slot_t] : nullptr;
+      p.q = slot_q >= 0 ? d_in[slot_q] : nullptr;
+      p.ff = d_out[0];
+      p.rh = d_out[1];
+      p.theta = d_out[2];
+      p.alevel = base.alevel + l0;
+      p.blevel = base.blevel + l0;
+      p.wind_all_defined = base.wind_all_defined + l0;
+      p.thermo_all_defined = base.thermo_all_defined + l0;
+      p.n_undefined = base.n_undefined + l0;
+      return mifc::launch_derived_levels(p, stream);
+    };
+    if (!mifc::hostpipe_run(c->pipe, n, nlev, n_in, h_in, 3, h_out, launch, &c->err))
+      return 0;
+    MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, 3 * sizeof(u64) * (size_t)nlev, hipMemcpyDeviceToHost, c->stream));
+    MIFC_HIP(c, hipStreamSynchronize(c->stream));
+    const u64* cnt = pinned_counts(c);
+    for (int l = 0; l < nlev; ++l) {
+      if (ff && fdef_ff)
+        fdef_ff[l] = mifc_classify(cnt[l], (u64)n);
+      if (rh && fdef_rh)
+        fdef_rh[l] = mifc_classify(cnt[nlev + l], (u64)n);
+      if (theta && fdef_theta)
+        fdef_theta[l] = mifc_classify(cnt[2 * nlev + l], (u64)n);
+    }
+    return 1;
+  }
   const float* du = ff ? stage_in(c, 0, u, nb, memkind, &ok) : nullptr;
   const float* dv = ff ? stage_in(c, 1, v, nb, memkind, &ok) : nullptr;
   const float* dt = (rh || theta) ? stage_in(c, 2, t, nb, memkind, &ok) : nullptr;

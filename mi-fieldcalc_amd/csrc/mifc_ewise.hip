@@ -385,9 +385,9 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
     if (CHECK && want_ff)
       wave_count_add(P.n_undefined + lev, bad_ff);
     if (want_rh)
-      wave_count_add(P.n_undefined + P.nlev + lev, bad_rh);
+      wave_count_add(P.n_undefined + (P.count_stride ? P.count_stride : P.nlev) + lev, bad_rh);
     if (CHECK && want_th)
-      wave_count_add(P.n_undefined + 2 * P.nlev + lev, bad_th);
+      wave_count_add(P.n_undefined + 2 * (P.count_stride ? P.count_stride : P.nlev) + lev, bad_th);
   }
 }
 
@@ -405,6 +405,8 @@ hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream)
   for (int l0 = 0; l0 < prm.nlev; l0 += 65535) {
     DerivedParams p = prm;
     const int nl = (prm.nlev - l0 > 65535) ? 65535 : (prm.nlev - l0);
+    p.count_stride = prm.count_stride ? prm.count_stride : prm.nlev;
+    p.nlev = nl;
     // shift the per-level pointers; counters keep the full-batch layout
     const size_t off = (size_t)l0 * (size_t)prm.n;
     p.u = prm.u ? prm.u + off : nullptr;

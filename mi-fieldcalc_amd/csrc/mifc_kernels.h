@@ -67,7 +67,8 @@ struct DerivedParams
   const unsigned char* thermo_all_defined; // device u8[nlev]
   int every_level_all_defined;             // host hint: skip all tests and counting
   float undef;
-  u64* n_undefined; // device u64[3*nlev]: ff | rh | theta
+  u64* n_undefined; // device u64[3*count_stride]: ff | rh | theta
+  int count_stride; // levels of the WHOLE batch when this launch is a chunk of it (0: nlev)
   // small batches (nlev <= 8, e.g. the single level of BASELINE.json config 2)
   // carry the per-level scalars in the kernel arguments: no upload before the launch
   int n_inline; // != 0: use the arrays below instead of the device arrays above

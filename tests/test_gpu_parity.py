@@ -473,6 +473,31 @@ def test_hlevel_derived_levels(gpu_ctx, oracle, mode):
     assert gpu_ctx.hlevel_derived_levels(u, v, t, q, ps, -a, b, fdef_wind=fw, fdef_thermo=ft) is None
 
 
+@pytest.mark.parametrize("want", [("ff", "rh", "theta"), ("theta",)])
+def test_hlevel_derived_levels_host_pipeline(gpu_ctx, want, monkeypatch):
+    """The fused ff / RH / theta batch from host memory streams through the device in
+    chunks (ragged last chunk); values and flags must equal the whole-batch path bit for bit."""
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 1440, 720, 18
+    u, v = synth.wind(nx, ny, 21, nlev=nlev)
+    t, q, ps = synth.thermo(nx, ny, 22, nlev=nlev)
+    a, b = synth.hybrid_levels(nlev)
+    fw = np.full(nlev, SOME, np.int32)
+    ft = fw.copy()
+    fw[::3] = ALL
+    for l in (1, 7, nlev - 1):
+        u[l] = synth.sprinkle_undef(u[l], 50 + l, 0.02)
+        t[l] = synth.sprinkle_undef(t[l], 60 + l, 0.02)
+    kw = dict(fdef_wind=fw, fdef_thermo=ft, want=want)
+    res, flags = gpu_ctx.hlevel_derived_levels(u, v, t, q, ps, a, b, **kw)
+    monkeypatch.setenv("MIFC_HOST_PIPELINE", "0")
+    res0, flags0 = gpu_ctx.hlevel_derived_levels(u, v, t, q, ps, a, b, **kw)
+    for k in want:
+        assert cases.same_bits(res[k], res0[k], nan_payload=False), k
+        assert np.array_equal(flags[k], flags0[k]), k
+
+
 # ------------------------------------------------------------------ headline size
 def test_headline_1440x720x137_properties(gpu_ctx, oracle):
     """Full BASELINE.json configuration on the device: sampled levels against the

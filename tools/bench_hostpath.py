@@ -57,6 +57,24 @@ def main():
     if a.only_batched:
         return
 
+    # BASELINE.json config 2 x nlev from host memory: fused ff + RH + theta
+    t, q, ps = synth.thermo(nx, ny, 0x5EED0000 + 1, nlev=nlev)
+    al, bl = synth.hybrid_levels(nlev)
+    outs = {"ff": np.empty_like(u), "rh": np.empty_like(u), "theta": np.empty_like(u)}
+    allf = [fc.ALL_DEFINED] * nlev
+
+    def derived():
+        assert ctx.hlevel_derived_levels(u, v, t, q, ps, al, bl, fdef_wind=allf, fdef_thermo=allf, out=outs) is not None
+
+    for pipe in ("1", "0"):
+        os.environ["MIFC_HOST_PIPELINE"] = pipe
+        dt = timed(derived, a.reps)
+        print(json.dumps({"case": "hlevel_derived_levels (ff, RH, theta) host pointers, " + ("chunked full-duplex pipeline" if pipe == "1" else "whole batch staged"),
+                          "nlev": nlev, "ms": 1e3 * dt, "mcells_per_s": cells / dt / 1e6, "in_GBps": cells * 16 / dt / 1e9, "out_GBps": cells * 12 / dt / 1e9}),
+              flush=True)
+    os.environ["MIFC_HOST_PIPELINE"] = "1"
+    del t, q, outs
+
     nl = min(nlev, 16)
 
     def per_field():
