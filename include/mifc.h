@@ -81,6 +81,11 @@ int mifc_copy_to_host(mifc_ctx* ctx, void* dst_host, const void* src_dev, size_t
  * operators read the caller's memory directly. */
 int mifc_hold_field(mifc_ctx* ctx, const float* host_field, size_t n_floats);
 int mifc_release_field(mifc_ctx* ctx, const float* host_field);
+/* Measurement aid (tools/bench_ops.py): kernel time of the calls made between begin and end,
+ * from HIP events recorded around every launch on the launch stream.  end returns milliseconds,
+ * -1 on error or after more than 16 launches. */
+int mifc_timing_begin(mifc_ctx* ctx);
+float mifc_timing_end_ms(mifc_ctx* ctx);
 /* miutil::checkDefined(size_t,size_t), FieldDefined.cc:62-70 */
 int mifc_classify(unsigned long long n_undefined, unsigned long long n);
 

@@ -127,6 +127,15 @@ class Context:
         if not self._lib.mifc_synchronize(self._ctx):
             raise RuntimeError(self.last_error())
 
+    def timing_begin(self):
+        """Measurement aid: bracket every kernel launch of the following calls with HIP events."""
+        if not self._lib.mifc_timing_begin(self._ctx):
+            raise RuntimeError(self.last_error())
+
+    def timing_end_ms(self):
+        """Summed kernel time (ms) of the calls since timing_begin(); -1 if unavailable."""
+        return float(self._lib.mifc_timing_end_ms(self._ctx))
+
     def hold_field(self, host_array):
         """Uploads a constant host field (map ratios, Coriolis parameter) once;
         host-pointer calls that are handed the same array then skip its upload.

@@ -18,6 +18,7 @@ _T = {
     "ctx": ctypes.c_void_p,
     "i": ctypes.c_int,
     "f": ctypes.c_float,
+    "fl": ctypes.c_float,  # float return value
     "s": ctypes.c_char_p,
     "p": ctypes.c_void_p,  # float* (host or device), passed as an address
     "pi": ctypes.c_void_p,  # int*  (host)
@@ -42,6 +43,8 @@ SIGNATURES = {
     "mifc_copy_to_host": ("i", ["ctx", "p", "p", "z"]),
     "mifc_hold_field": ("i", ["ctx", "p", "z"]),
     "mifc_release_field": ("i", ["ctx", "p"]),
+    "mifc_timing_begin": ("i", ["ctx"]),
+    "mifc_timing_end_ms": ("fl", ["ctx"]),
     "mifc_classify": ("i", ["u64", "u64"]),
     # elementwise
     "mifc_vectorabs": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),

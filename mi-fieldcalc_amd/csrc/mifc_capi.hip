@@ -193,7 +193,7 @@ int run_ewise(mifc_ctx* c, mifc::EwiseParams P, const float* in0, const float* i
   P.n_undefined = c->d_counts;
   if (P.count)
     MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64), c->stream));
-  MIFC_HIP(c, mifc::launch_ewise(P, c->stream));
+  MIFC_LAUNCH(c, mifc::launch_ewise(P, c->stream));
   if (P.count)
     MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   if (!fetch_out(c, 3, out, n, memkind))
@@ -340,7 +340,7 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
     if (!every_all)
       MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64) * (size_t)sc.nlev, hipMemcpyDeviceToHost, c->stream));
   } else {
-    MIFC_HIP(c, mifc::launch_stencil(P, c->stream));
+    MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
     if (!every_all)
       MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64) * (size_t)sc.nlev, hipMemcpyDeviceToHost, c->stream));
     if (!fetch_out(c, 5, sc.o0, nb, memkind) || !fetch_out(c, 6, sc.o1, nb, memkind))
@@ -417,6 +417,9 @@ void mifc_destroy(mifc_ctx* c)
     (void)hipHostFree(c->h_pinned);
   if (c->pinned_read)
     (void)hipEventDestroy(c->pinned_read);
+  for (hipEvent_t e : c->tev)
+    if (e)
+      (void)hipEventDestroy(e);
   mifc::hostpipe_destroy(c->pipe);
   for (const mifc_ctx::HeldField& h : c->held)
     (void)hipFree(h.dev);
@@ -551,6 +554,37 @@ int mifc_release_field(mifc_ctx* c, const float* host_field)
     }
   }
   return 0;
+}
+
+// Measurement aid: between begin and end every kernel launch of this context is bracketed by a
+// HIP event pair on its launch stream; end returns the summed kernel time in milliseconds
+// (-1 on error, or when more than 16 launches happened in between).
+int mifc_timing_begin(mifc_ctx* c)
+{
+  if (!c)
+    return 0;
+  c->err.clear();
+  for (hipEvent_t& e : c->tev)
+    if (!e)
+      MIFC_HIP(c, hipEventCreate(&e));
+  c->n_timed = 0;
+  c->timing = true;
+  return 1;
+}
+
+float mifc_timing_end_ms(mifc_ctx* c)
+{
+  if (!c || !c->timing)
+    return -1.f;
+  c->timing = false;
+  float total = 0.f;
+  for (int k = 0; k < c->n_timed; ++k) {
+    float ms = 0.f;
+    if (hipEventSynchronize(c->tev[2 * k + 1]) != hipSuccess || hipEventElapsedTime(&ms, c->tev[2 * k], c->tev[2 * k + 1]) != hipSuccess)
+      return -1.f;
+    total += ms;
+  }
+  return c->n_timed >= mifc_ctx::NTIMED ? -1.f : total;
 }
 
 int mifc_classify(unsigned long long n_undefined, unsigned long long n)
@@ -1111,7 +1145,7 @@ int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const flo
   }
   if (n_undefined_dev)
     MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64) * (size_t)nlev, c->stream));
-  MIFC_HIP(c, mifc::launch_stencil(P, c->stream));
+  MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
   return 1;
 }
 
@@ -1187,7 +1221,7 @@ static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u,
   if (prepared_only) // the caller launches chunk by chunk (host pipeline)
     *prepared_only = P;
   else
-    MIFC_HIP(c, mifc::launch_derived_levels(P, c->stream));
+    MIFC_LAUNCH(c, mifc::launch_derived_levels(P, c->stream));
   if (every_all_out)
     *every_all_out = every_all;
   return 1;
@@ -1358,7 +1392,7 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny
   }
   if (n_undefined_dev)
     MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64), c->stream));
-  MIFC_HIP(c, mifc::launch_stencil(P, c->stream));
+  MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
   return 1;
 }
 

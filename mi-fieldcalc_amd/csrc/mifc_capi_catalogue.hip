@@ -64,7 +64,7 @@ int run_pointwise(mifc_ctx* c, int nx, int ny, PwCall& pc, float* out, int* fdef
   P.n_undefined = c->d_counts;
   if (P.count)
     MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64), c->stream));
-  MIFC_HIP(c, mifc::launch_pointwise(P, c->stream));
+  MIFC_LAUNCH(c, mifc::launch_pointwise(P, c->stream));
   if (P.count) {
     if (!pinned_acquire(c))
       return 0;
@@ -150,7 +150,7 @@ int run_ensemble(mifc_ctx* c, mifc::EnsembleParams P, int nx, int ny, const floa
   if (!pinned_acquire(c))
     return 0;
   MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64), c->stream));
-  MIFC_HIP(c, mifc::launch_ensemble(P, c->stream));
+  MIFC_LAUNCH(c, mifc::launch_ensemble(P, c->stream));
   MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   if (!fetch_out(c, 9, out, n, memkind))
     return 0;
@@ -462,7 +462,7 @@ int mifc_cvtemp(mifc_ctx* c, int nx, int ny, const float* tinp, int compute, flo
     if (!ok || !ensure_levels(c, 1) || !pinned_acquire(c))
       return 0;
     MIFC_HIP(c, hipMemsetAsync(c->d_counts + 1, 0, 2 * sizeof(u64), c->stream));
-    MIFC_HIP(c, mifc::launch_mean_defined(d_in, (int)n, *fdefined == MIFC_ALL_DEFINED, undef, reinterpret_cast<double*>(c->d_counts + 1),
+    MIFC_LAUNCH(c, mifc::launch_mean_defined(d_in, (int)n, *fdefined == MIFC_ALL_DEFINED, undef, reinterpret_cast<double*>(c->d_counts + 1),
                                           reinterpret_cast<unsigned long long*>(c->d_counts + 2), c->stream));
     MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c) + 1, c->d_counts + 1, 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     MIFC_HIP(c, hipStreamSynchronize(c->stream));
@@ -591,7 +591,7 @@ int mifc_shapiro2_filter(mifc_ctx* c, int nx, int ny, const float* field, float*
   P.f2 = static_cast<float*>(c->slot[8]);
   P.mask_x = all ? nullptr : static_cast<unsigned char*>(c->slot[9]);
   P.mask_y = all ? nullptr : static_cast<unsigned char*>(c->slot[9]) + n;
-  MIFC_HIP(c, mifc::launch_shapiro2(P, c->stream));
+  MIFC_LAUNCH(c, mifc::launch_shapiro2(P, c->stream));
   if (!fetch_out(c, 5, fsmooth, n, memkind))
     return 0;
   MIFC_HIP(c, hipStreamSynchronize(c->stream));

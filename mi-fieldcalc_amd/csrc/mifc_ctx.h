@@ -45,6 +45,12 @@ struct mifc_ctx
     float* dev;
   };
   std::vector<HeldField> held;
+  // measurement aid (mifc_timing_begin / mifc_timing_end_ms): HIP event pairs around every
+  // kernel launch of the calls in between, on the stream the kernels are launched on
+  static const int NTIMED = 16;
+  bool timing = false;
+  int n_timed = 0;
+  hipEvent_t tev[2 * NTIMED] = {nullptr};
 };
 
 namespace mifc_host {
@@ -58,6 +64,19 @@ bool fail(mifc_ctx* c, const char* what, hipError_t e);
       mifc_host::fail((c), #call, e_);       \
       return 0;                              \
     }                                        \
+  } while (0)
+
+// launches wrapped in event pairs while a timing section is open
+#define MIFC_LAUNCH(c, call)                                                      \
+  do {                                                                            \
+    const bool timed_ = (c)->timing && (c)->n_timed < mifc_ctx::NTIMED;           \
+    if (timed_)                                                                   \
+      (void)hipEventRecord((c)->tev[2 * (c)->n_timed], (c)->stream);              \
+    MIFC_HIP(c, call);                                                            \
+    if (timed_) {                                                                 \
+      (void)hipEventRecord((c)->tev[2 * (c)->n_timed + 1], (c)->stream);          \
+      (c)->n_timed += 1;                                                          \
+    }                                                                             \
   } while (0)
 
 bool ensure_slot(mifc_ctx* c, int s, size_t bytes);
