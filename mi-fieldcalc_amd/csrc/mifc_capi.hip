@@ -437,7 +437,7 @@ int mifc_set_stream(mifc_ctx* c, void* hip_stream)
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   c->stream = static_cast<hipStream_t>(hip_stream); // null = HIP's default stream
   return 1;
 }
@@ -454,7 +454,7 @@ int mifc_synchronize(mifc_ctx* c)
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   MIFC_HIP(c, hipStreamSynchronize(c->stream));
   return 1;
 }
@@ -476,7 +476,7 @@ int mifc_device_free(mifc_ctx* c, void* dptr)
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   MIFC_HIP(c, hipFree(dptr));
   return 1;
 }
@@ -485,7 +485,7 @@ int mifc_copy_to_device(mifc_ctx* c, void* dst_dev, const void* src_host, size_t
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   MIFC_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
   MIFC_HIP(c, hipStreamSynchronize(c->stream));
   return 1;
@@ -495,7 +495,7 @@ int mifc_copy_to_host(mifc_ctx* c, void* dst_host, const void* src_dev, size_t b
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   MIFC_HIP(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
   MIFC_HIP(c, hipStreamSynchronize(c->stream));
   return 1;
@@ -510,7 +510,7 @@ int mifc_hold_field(mifc_ctx* c, const float* host_field, size_t n_floats)
 {
   if (!c || !host_field || n_floats == 0)
     return 0;
-  c->err.clear();
+  enter(c);
   for (mifc_ctx::HeldField& h : c->held) {
     if (h.host == host_field) { // refresh (content or size may have changed)
       if (h.n < n_floats) {
@@ -544,7 +544,7 @@ int mifc_release_field(mifc_ctx* c, const float* host_field)
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   for (size_t k = 0; k < c->held.size(); ++k) {
     if (c->held[k].host == host_field) {
       MIFC_HIP(c, hipStreamSynchronize(c->stream));
@@ -563,7 +563,7 @@ int mifc_timing_begin(mifc_ctx* c)
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   for (hipEvent_t& e : c->tev)
     if (!e)
       MIFC_HIP(c, hipEventCreate(&e));
@@ -602,7 +602,7 @@ int mifc_vectorabs(mifc_ctx* c, int nx, int ny, const float* u, const float* v, 
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (nx * ny <= 0) { // empty loop, checkDefined(0, 0)
     *fdefined = MIFC_ALL_DEFINED;
     return 1;
@@ -616,7 +616,7 @@ int mifc_pleveltemp(mifc_ctx* c, int nx, int ny, const float* tinp, float p, con
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (p <= 0) // FieldCalculations.cc:330
     return 0;
   if (compute < 3) { // :340-345
@@ -647,7 +647,7 @@ int mifc_hleveltemp(mifc_ctx* c, int nx, int ny, const float* tinp, const float*
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (compute < 3) { // :1060-1065
     if (unit_is(unit, "celsius"))
       compute = 1;
@@ -673,7 +673,7 @@ int mifc_aleveltemp(mifc_ctx* c, int nx, int ny, const float* tinp, const float*
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (compute <= 0 || compute >= 6) // :1319
     return 0;
   if (compute < 3) {
@@ -708,7 +708,7 @@ int mifc_plevelhum(mifc_ctx* c, int nx, int ny, const float* t, const float* hum
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (p <= 0 || compute <= 0 || compute >= 13) // :419
     return 0;
   if (compute > 8 && unit_is(unit, "celsius")) // :422-425
@@ -761,7 +761,7 @@ int mifc_hlevelhum(mifc_ctx* c, int nx, int ny, const float* t, const float* hum
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (compute <= 0 || compute >= 13) // :1168
     return 0;
   if (bad_hlevel(alevel, blevel)) // :1170
@@ -791,7 +791,7 @@ int mifc_alevelhum(mifc_ctx* c, int nx, int ny, const float* t, const float* hum
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (compute <= 0 || compute >= 13) // :1414
     return 0;
   if (compute > 8 && unit_is(unit, "celsius")) // :1417-1420
@@ -819,7 +819,7 @@ int mifc_cvhum(mifc_ctx* c, int nx, int ny, const float* t, const float* huminp,
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   float unit_scale = 100; // :1746-1750
   if (compute == 1 && unit_is(unit, "celsius"))
     compute = 2;
@@ -845,7 +845,7 @@ int mifc_relvort(mifc_ctx* c, int nx, int ny, const float* u, const float* v, co
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   const StencilCall sc = {mifc::ST_RELVORT, nx, ny, 1, u, v, xmapr, ymapr, nullptr, rvort, nullptr};
   return run_stencil(c, sc, fdefined, undef, memkind);
 }
@@ -855,7 +855,7 @@ int mifc_absvort(mifc_ctx* c, int nx, int ny, const float* u, const float* v, co
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   const StencilCall sc = {mifc::ST_ABSVORT, nx, ny, 1, u, v, xmapr, ymapr, fcoriolis, avort, nullptr};
   return run_stencil(c, sc, fdefined, undef, memkind);
 }
@@ -865,7 +865,7 @@ int mifc_divergence(mifc_ctx* c, int nx, int ny, const float* u, const float* v,
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   const StencilCall sc = {mifc::ST_DIVERGENCE, nx, ny, 1, u, v, xmapr, ymapr, nullptr, diverg, nullptr};
   return run_stencil(c, sc, fdefined, undef, memkind);
 }
@@ -875,7 +875,7 @@ int mifc_gradient(mifc_ctx* c, int nx, int ny, const float* field, const float* 
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (compute < 1 || compute > 4) // :2064 (size check comes first in the reference, both return false)
     return 0;
   const int op = mifc::ST_GRAD_X + (compute - 1);
@@ -888,7 +888,7 @@ int mifc_plevelgwind_xcomp(mifc_ctx* c, int nx, int ny, const float* z, const fl
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   (void)xmapr; // unused by the reference as well (:638)
   const StencilCall sc = {mifc::ST_GWIND_X, nx, ny, 1, z, nullptr, nullptr, ymapr, fcoriolis, ug, nullptr};
   return run_stencil(c, sc, fdefined, undef, memkind);
@@ -899,7 +899,7 @@ int mifc_plevelgwind_ycomp(mifc_ctx* c, int nx, int ny, const float* z, const fl
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   (void)ymapr;
   // the reference lacks the nx<3||ny<3 guard here and would read out of bounds;
   // this implementation returns false instead
@@ -912,7 +912,7 @@ int mifc_plevelgvort(mifc_ctx* c, int nx, int ny, const float* z, const float* x
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   const StencilCall sc = {mifc::ST_GVORT, nx, ny, 1, z, nullptr, xmapr, ymapr, fcoriolis, gvort, nullptr};
   return run_stencil(c, sc, fdefined, undef, memkind);
 }
@@ -922,7 +922,7 @@ int mifc_ilevelgwind(mifc_ctx* c, int nx, int ny, const float* mpot, const float
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   const StencilCall sc = {mifc::ST_IGWIND, nx, ny, 1, mpot, nullptr, xmapr, ymapr, fcoriolis, ug, vg};
   return run_stencil(c, sc, fdefined, undef, memkind);
 }
@@ -934,7 +934,7 @@ int mifc_advection(mifc_ctx* c, int nx, int ny, const float* f, const float* u, 
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   StencilCall sc = {mifc::ST_ADVECTION, nx, ny, 1, f, u, xmapr, ymapr, nullptr, advec, nullptr};
   sc.f2 = v;
   sc.scale = (float)(-3600. * (double)hours); // FieldCalculations.cc:1963
@@ -946,7 +946,7 @@ int mifc_jacobian(mifc_ctx* c, int nx, int ny, const float* field1, const float*
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   const StencilCall sc = {mifc::ST_JACOBIAN, nx, ny, 1, field1, field2, xmapr, ymapr, nullptr, fjacobian, nullptr};
   return run_stencil(c, sc, fdefined, undef, memkind);
 }
@@ -956,7 +956,7 @@ static int momentum_coordinate(mifc_ctx* c, int op, int nx, int ny, const float*
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (nx < 3 || ny < 3) // :2363, :2397
     return 0;
   mifc::EwiseParams P = ewise_base(op, nx, ny, fdefined, undef);
@@ -985,7 +985,7 @@ int mifc_thermalFrontParameter(mifc_ctx* c, int nx, int ny, const float* tx, con
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (nx < 3 || ny < 3) // gradient() :2004
     return 0;
   const size_t n = (size_t)nx * ny;
@@ -1019,7 +1019,7 @@ int mifc_plevelqvector(mifc_ctx* c, int nx, int ny, const float* z, const float*
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (p <= 0.0 || nx < 3 || ny < 3) // :526-530
     return 0;
   float tscale;
@@ -1068,7 +1068,7 @@ int mifc_vortdiv_levels(mifc_ctx* c, int nx, int ny, int nlev, const float* u, c
 {
   if (!c || (!rvort && !diverg))
     return 0;
-  c->err.clear();
+  enter(c);
   const StencilCall sc = {mifc::ST_VORTDIV, nx, ny, nlev, u, v, xmapr, ymapr, nullptr, rvort, diverg};
   return run_stencil(c, sc, fdefined, undef, memkind);
 }
@@ -1078,7 +1078,7 @@ int mifc_stencil_levels(mifc_ctx* c, int op, int nx, int ny, int nlev, const flo
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (op < mifc::ST_RELVORT || op > mifc::ST_IGWIND || !f0 || !out0)
     return 0;
   const bool wind = (op <= mifc::ST_VORTDIV);
@@ -1094,7 +1094,7 @@ int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const flo
 {
   if (!c || (!rvort && !diverg))
     return 0;
-  c->err.clear();
+  enter(c);
   if (nx < 3 || ny < 3 || nlev < 1)
     return 0;
   if (!ensure_levels(c, (size_t)nlev))
@@ -1233,7 +1233,7 @@ int mifc_hlevel_derived_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, co
 {
   if (!c || !n_undefined_dev)
     return 0;
-  c->err.clear();
+  enter(c);
   if ((nx * ny) % 4 != 0) {
     c->err = "mifc_hlevel_derived_levels: nx*ny must be a multiple of 4 (use the per-field operators otherwise)";
     return 0;
@@ -1247,7 +1247,7 @@ int mifc_hlevel_derived_levels(mifc_ctx* c, int nx, int ny, int nlev, const floa
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (nlev < 1 || nx * ny <= 0)
     return 0;
   if ((nx * ny) % 4 != 0) {
@@ -1355,7 +1355,7 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny
 {
   if (!c || (!rvort && !diverg))
     return 0;
-  c->err.clear();
+  enter(c);
   if (nx < 3 || ny_global < 3 || ny_local < 1 || j0 < 0 || j0 + ny_local > ny_global)
     return 0;
   // a slab that owns a global edge row must also own the row it is filled from
@@ -1400,7 +1400,7 @@ int mifc_bench_stream2(mifc_ctx* c, int variant, int blocks, float* dst0, float*
 {
   if (!c)
     return 0;
-  c->err.clear();
+  enter(c);
   if (n_floats % 4 != 0)
     return 0;
   MIFC_HIP(c, mifc::launch_stream2(variant, blocks, dst0, dst1, src0, src1, n_floats, c->stream));

@@ -162,7 +162,7 @@ int run_ensemble(mifc_ctx* c, mifc::EnsembleParams P, int nx, int ny, const floa
 #define CTX_OR_FAIL(c) \
   if (!(c))            \
     return 0;          \
-  (c)->err.clear()
+  mifc_host::enter(c)
 
 } // namespace
 

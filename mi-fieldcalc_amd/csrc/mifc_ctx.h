@@ -57,6 +57,16 @@ namespace mifc_host {
 
 bool fail(mifc_ctx* c, const char* what, hipError_t e);
 
+// Start of every entry point: forget the last error and make the context's device current
+// for the calling thread (a process may hold contexts on several GPUs).
+inline void enter(mifc_ctx* c)
+{
+  c->err.clear();
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != c->device)
+    (void)hipSetDevice(c->device);
+}
+
 #define MIFC_HIP(c, call)                    \
   do {                                       \
     hipError_t e_ = (call);                  \
