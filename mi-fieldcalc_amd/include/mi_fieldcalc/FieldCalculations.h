@@ -149,6 +149,16 @@ bool vesselIcingOverland(int nx, int ny, const float* airtemp, const float* seat
                          const float* aice, float* icing, ValuesDefined& fDefined, float undef);
 bool vesselIcingMertins(int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v, const float* sal,
                         const float* aice, float* icing, ValuesDefined& fDefined, float undef);
+// The two iterative vessel-icing models are declared so that callers (the reference's
+// pybind11 module among them) compile and link unchanged; they are not built on the GPU
+// yet and return false without touching their outputs -- they do not compute on the CPU.
+bool vesselIcingModStall(int nx, int ny, const float* sal, const float* wave, const float* x_wind, const float* y_wind, const float* airtemp,
+                         const float* rh, const float* sst, const float* p, const float* Pw, const float* aice, const float* depth,
+                         const float vs, const float alpha, const float zmin, const float zmax, float* icing, ValuesDefined& fDefined, float undef);
+bool vesselIcingMincog(int nx, int ny, const float* sal, const float* wave, const float* x_wind, const float* y_wind, const float* airtemp,
+                       const float* rh, const float* sst, const float* p, const float* Pw, const float* aice, const float* depth,
+                       const float vs, const float alpha, const float zmin, const float zmax, const int alt, float* icing, ValuesDefined& fDefined,
+                       float undef);
 
 // ---- field algebra ----------------------------------------------------------------
 void minvalueFields(int nx, int ny, const float* field1, const float* field2, float* fres, ValuesDefined& fDefined, float undef);

@@ -337,6 +337,19 @@ bool vesselIcingMertins(int nx, int ny, const float* airtemp, const float* seate
   MIFC_FORWARD(mifc_vesselIcingMertins(context(), nx, ny, airtemp, seatemp, u, v, sal, aice, icing, f.ptr(), undef, MIFC_MEM_HOST));
 }
 
+// Not built on the GPU yet (FieldCalculationsVesselIcing.cc:182, :677): "false", like any other failure.
+bool vesselIcingModStall(int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                         const float*, const float*, const float*, const float, const float, const float, const float, float*, ValuesDefined&, float)
+{
+  return false;
+}
+bool vesselIcingMincog(int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                       const float*, const float*, const float*, const float, const float, const float, const float, const int, float*, ValuesDefined&,
+                       float)
+{
+  return false;
+}
+
 #define MIFC_FORWARD_VOID(call) \
   FlagIO f(fDefined);           \
   (void)(call)
