@@ -5,6 +5,8 @@
 #ifndef MI_FIELDCALC_METCONSTANTS_H
 #define MI_FIELDCALC_METCONSTANTS_H
 
+#include <string>
+
 namespace miutil {
 namespace constants {
 
@@ -17,6 +19,9 @@ const float kappa = r / cp;
 const float g = 9.8;
 const float ginv = 1. / g;
 const float rhmin = 0.02, rhmax = 1.00;
+
+const double ft_per_m = 3.2808399;
+const double ms2knots = 3600.0 / 1852.0, knots2ms = 1 / ms2knots;
 
 // e_sat over water at -100, -95, ... +100 degrees Celsius
 const int N_EWT = 41;
@@ -45,7 +50,27 @@ private:
   int l;
 };
 
+// standard pressure levels (hPa) and the flight levels (100 ft) drawn for them
+// (reference MetConstants.h:86-92; pressure2FlightLevel interpolates in these)
+const int nLevelTable = 16;
+const float pLevelTable[nLevelTable] = {1000, 925, 850, 800, 700, 500, 400, 300, 250, 200, 150, 100, 70, 50, 30, 10};
+const float fLevelTable[nLevelTable] = {5, 25, 50, 65, 100, 185, 235, 300, 340, 385, 445, 530, 605, 675, 780, 1020};
+const float fLevelTable_old[nLevelTable] = {0, 25, 50, 70, 100, 180, 240, 300, 340, 390, 450, 530, 600, 700, 800, 999};
+
+// ICAO standard atmosphere (doc 7488), pressure in hPa, geopotential altitude in m
+double ICAO_geo_altitude_from_pressure(double pressure);
+double ICAO_pressure_from_geo_altitude(double altitude);
+// altitude (m) -> flight level rounded to 500 ft, and back (no rounding)
+int FL_from_geo_altitude(double a);
+double geo_altitude_from_FL(double fl);
+
+const std::string VerticalName[7] = {"none", "pressure", "hybrid", "atmospheric", "isentropic", "oceandepth", "other"};
+
 } // namespace constants
+
+inline float ms2knots(float ff) { return ff * miutil::constants::ms2knots; }
+inline float knots2ms(float ff) { return ff * miutil::constants::knots2ms; }
+
 } // namespace miutil
 
 #endif // MI_FIELDCALC_METCONSTANTS_H

@@ -195,6 +195,55 @@ def test_reference_pybind_module_builds_unchanged_against_this_library(built, tm
         assert result == "abshum None"  # no GPU: the operator returns false, the module None -- no CPU fallback
 
 
+_ICAO = {
+    "alt": "_ZN6miutil9constants31ICAO_geo_altitude_from_pressureEd",
+    "prs": "_ZN6miutil9constants31ICAO_pressure_from_geo_altitudeEd",
+    "fl": "_ZN6miutil9constants20FL_from_geo_altitudeEd",
+    "alt_fl": "_ZN6miutil9constants20geo_altitude_from_FLEd",
+}
+# ICAO doc 7488, as in the reference's test/MetConstantsTest.cc:39-58 (pressure hPa, altitude m)
+_DOC7488 = [(8.7, 31985), (10.0, 31055), (11.1, 30360), (19.4, 26680), (97.3, 16353), (139.5, 14069), (244.1, 10517), (354.2, 8035), (459.7, 6189),
+            (590.8, 4324), (739.7, 2576), (840.7, 1547), (936.8, 657), (1010.0, 27), (1020.0, -56), (1050.0, -302), (1130.0, -929)]
+
+
+def _icao(libpath):
+    lib = ctypes.CDLL(libpath)
+    fns = {}
+    for k, sym in _ICAO.items():
+        f = getattr(lib, sym)
+        f.argtypes = [ctypes.c_double]
+        f.restype = ctypes.c_int if k == "fl" else ctypes.c_double
+        fns[k] = f
+    return fns
+
+
+def test_icao_standard_atmosphere_helpers(built):
+    """The host-side helpers of MetConstants.h (not operators, no GPU): the reference's own
+    known answers (test/MetConstantsTest.cc:61-120) and, where the compiled reference is
+    available, agreement with it over the whole range."""
+    mine = _icao(CXXLIB)
+    for p, h in _DOC7488:
+        assert abs(mine["alt"](p) - h) <= 1.55  # :66
+        assert abs(mine["prs"](h) - p) <= 0.01 * p  # :101
+    for p, fl in ((600, 140), (500, 185), (400, 235), (300, 300), (250, 340), (200, 385), (150, 445)):  # :49-58, :72-80
+        assert mine["fl"](mine["alt"](p)) == fl
+    ptab = [1000, 925, 850, 800, 700, 500, 400, 300, 250, 200, 150, 100, 70, 50, 30, 10]
+    ftab = [5, 25, 50, 65, 100, 185, 235, 300, 340, 385, 445, 530, 605, 675, 780, 1020]
+    for p, fl in zip(ptab, ftab):  # :82-90
+        assert mine["fl"](mine["alt"](p)) == fl
+    assert abs(mine["alt_fl"](100) - 10000 / 3.2808399) < 1e-9
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libmifc_ref.so")
+    if os.path.exists(ref_path):
+        ref = _icao(ref_path)
+        for p in np.geomspace(0.002, 1200.0, 400):
+            a, b = mine["alt"](float(p)), ref["alt"](float(p))
+            assert abs(a - b) <= 1e-6 * max(1.0, abs(b)), p
+        for h in np.linspace(-1500.0, 90000.0, 400):
+            a, b = mine["prs"](float(h)), ref["prs"](float(h))
+            assert abs(a - b) <= 1e-9 * max(1.0, abs(b)), h
+            assert mine["fl"](float(h)) == ref["fl"](float(h))
+
+
 def test_shard_range_partitions_exactly():
     from mi_fieldcalc_amd.sharding import shard_range, slab_rows
 
