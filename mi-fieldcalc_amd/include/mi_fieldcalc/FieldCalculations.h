@@ -11,9 +11,11 @@
 // caller that keeps its fields resident in HBM uses the mifc_* entry points
 // (or the *_levels batched forms) with MIFC_MEM_DEVICE directly.
 //
-// Not provided by this build: the operators outside the hot path (stability
-// indices, field algebra, ensemble statistics, neighbourhood functions,
-// vessel icing ...); link the reference library for those.
+// Every function the reference header declares is declared here and exported
+// by libmi-fieldcalc.so with the same mangled name, so existing callers compile
+// and link unchanged.  Four of them are not built on the GPU and return false
+// (they never compute on the CPU): vesselIcingModStall, vesselIcingMincog,
+// neighbourProbFunctions, neighbourFunctions.
 #ifndef MI_FIELDCALC_FIELDCALCULATIONS_H
 #define MI_FIELDCALC_FIELDCALCULATIONS_H
 
@@ -186,6 +188,13 @@ bool stddevValue(int nx, int ny, const std::vector<float*>& fields, const std::v
 bool extremeValue(int compute, int nx, int ny, const std::vector<float*>& fields, float* fres, ValuesDefined& fDefined, float undef);
 bool probability(int compute, int nx, int ny, const std::vector<float*>& fields, const std::vector<ValuesDefined>& fDefinedIn,
                  const std::vector<float>& limits, float* fres, ValuesDefined& fDefinedOut, float undef);
+
+// Neighbourhood statistics: declared for link compatibility, not built on the GPU
+// (outside the accelerated path); they return false and do not compute on the CPU.
+bool neighbourProbFunctions(int nx, int ny, const float* field, const std::vector<float>& constants, int compute,
+                            float* fres, ValuesDefined& fDefined, float undef);
+bool neighbourFunctions(int nx, int ny, const float* field, const std::vector<float>& constants, int compute,
+                        float* fres, ValuesDefined& fDefined, float undef);
 
 // ---- extensions of this implementation (not in the reference) -----------------
 // Fused relvort + divergence for nlev levels stored [nlev][ny][nx]; xmapr/ymapr

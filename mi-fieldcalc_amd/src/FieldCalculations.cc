@@ -350,6 +350,15 @@ bool vesselIcingMincog(int, int, const float*, const float*, const float*, const
   return false;
 }
 
+bool neighbourProbFunctions(int, int, const float*, const std::vector<float>&, int, float*, ValuesDefined&, float)
+{
+  return false; // FieldCalculations.cc:2862, not built
+}
+bool neighbourFunctions(int, int, const float*, const std::vector<float>&, int, float*, ValuesDefined&, float)
+{
+  return false; // FieldCalculations.cc:2955, not built
+}
+
 #define MIFC_FORWARD_VOID(call) \
   FlagIO f(fDefined);           \
   (void)(call)

@@ -270,3 +270,22 @@ def test_synth_is_deterministic():
     assert xm.dtype == np.float32 and np.all(np.abs(fc) >= 1e-5) and np.all(xm >= ym - 1e-12)
     a, b = synth.hybrid_levels(137)
     assert np.all(a >= 0) and np.all(b >= 0) and np.all(b <= 1) and not np.any((a == 0) & (b == 0))
+
+
+def test_cxx_library_exports_the_reference_symbols(built):
+    """Binary drop-in: every miutil::fieldcalc / miutil::constants function the compiled
+    reference exports is exported by libmi-fieldcalc.so under the same mangled name."""
+    ref_path = os.path.join(ROOT, "oracle", "_ref", "libmifc_ref.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("compiled reference not available")
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+
+    ref = {s for s in exported(ref_path) if s.startswith("_ZN6miutil")}
+    mine = exported(CXXLIB)
+    # internal helpers the reference happens to export: its OpenMP thread heuristic and a file-local predicate
+    internal = {s for s in ref if "compute_num_threads" in s or "bad_hlevel" in s}
+    assert len(ref) > 70
+    assert not (ref - internal - mine), sorted(ref - internal - mine)
