@@ -977,9 +977,42 @@ int mifc_momentumYcoordinate(mifc_ctx* c, int nx, int ny, const float* u, const 
   return momentum_coordinate(c, mifc::EW_MOMENTUM_Y, nx, ny, u, ymapr, fcoriolis, fcoriolisMin, nxy, fdefined, undef, memkind);
 }
 
-// thermalFrontParameter, FieldCalculations.cc:2266-2309: two passes with an
-// intermediate |grad T| field that lives in the context's scratch.  The second
-// pass takes its "all defined" from the flag the first pass returned (:2286).
+// One launch of mifc_fused2.hip on device pointers.  Returns 0 on error, 1 when
+// the result stands (flag written), 2 when the caller has to take the
+// multi-pass path after all (see the thermalFrontParameter note below).
+static int run_fused2(mifc_ctx* c, mifc::Fused2Params& P, int* fdefined)
+{
+  if (!ensure_levels(c, 4) || !pinned_acquire(c))
+    return 0;
+  P.counts = c->d_counts;
+  P.check = (*fdefined != MIFC_ALL_DEFINED) ? 1 : 0;
+  if (!mifc::fused2_supported(P))
+    return 2;
+  MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, 3 * sizeof(u64), c->stream));
+  MIFC_LAUNCH(c, mifc::launch_fused2(P, c->stream));
+  MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  const u64* n = pinned_counts(c);
+  // thermalFrontParameter's second pass tests its inputs only if the first pass
+  // left something undefined (:2286).  The kernel ran it tested; if the first
+  // pass turned out clean AND the test rejected a cell the untested loop would
+  // have computed (a NaN gradient from defined inputs), the result differs.
+  if (P.op == mifc::F2_TFP && P.check && n[0] == 0 && n[2] != 0)
+    return 2;
+  *fdefined = mifc_classify(n[1], (u64)P.nx * (u64)P.ny - 2 * (u64)P.nx); // :2303, :590
+  return 1;
+}
+
+static bool fused2_enabled()
+{
+  const char* e = std::getenv("MIFC_FUSED2"); // "0": always the multi-pass path (A/B measurements, tests)
+  return !(e && e[0] == '0');
+}
+
+// thermalFrontParameter, FieldCalculations.cc:2266-2309.  One fused launch where
+// the grid allows it; otherwise two passes with an intermediate |grad T| field
+// that lives in the context's scratch.  The second pass takes its "all defined"
+// from the flag the first pass returned (:2286).
 int mifc_thermalFrontParameter(mifc_ctx* c, int nx, int ny, const float* tx, const float* xmapr, const float* ymapr, float* tfp, int* fdefined,
                                float undef, int memkind)
 {
@@ -995,7 +1028,30 @@ int mifc_thermalFrontParameter(mifc_ctx* c, int nx, int ny, const float* tx, con
   const float* d_xm = stage_in(c, 2, xmapr, n, memkind, &ok);
   const float* d_ym = stage_in(c, 3, ymapr, n, memkind, &ok);
   float* d_out = stage_out(c, 5, tfp, n, memkind, &ok);
-  if (!ok || !ensure_slot(c, 8, n * sizeof(float)))
+  if (!ok)
+    return 0;
+  if (fused2_enabled()) {
+    mifc::Fused2Params F;
+    std::memset(&F, 0, sizeof F);
+    F.op = mifc::F2_TFP;
+    F.nx = nx;
+    F.ny = ny;
+    F.a = d_tx;
+    F.xmapr = d_xm;
+    F.ymapr = d_ym;
+    F.out = d_out;
+    F.undef = undef;
+    const int r = run_fused2(c, F, fdefined);
+    if (r == 0)
+      return 0;
+    if (r == 1) {
+      if (!fetch_out(c, 5, tfp, n, memkind))
+        return 0;
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+      return 1;
+    }
+  }
+  if (!ensure_slot(c, 8, n * sizeof(float)))
     return 0;
   float* d_absdelt = static_cast<float*>(c->slot[8]);
   const StencilCall pass1 = {mifc::ST_GRAD_ABS, nx, ny, 1, d_tx, nullptr, d_xm, d_ym, nullptr, d_absdelt, nullptr};
@@ -1039,7 +1095,35 @@ int mifc_plevelqvector(mifc_ctx* c, int nx, int ny, const float* z, const float*
   const float* d_ym = stage_in(c, 3, ymapr, n, memkind, &ok);
   const float* d_fc = stage_in(c, 4, fcoriolis, n, memkind, &ok);
   float* d_out = stage_out(c, 5, qcomp, n, memkind, &ok);
-  if (!ok || !ensure_slot(c, 8, n * sizeof(float)) || !ensure_slot(c, 9, n * sizeof(float)))
+  if (!ok)
+    return 0;
+  const float cscale = (float)((double)(-287.f) / ((double)p * 100.)); // :564
+  if (fused2_enabled()) {
+    mifc::Fused2Params F;
+    std::memset(&F, 0, sizeof F);
+    F.op = compute < 3 ? mifc::F2_QVEC_X : mifc::F2_QVEC_Y;
+    F.nx = nx;
+    F.ny = ny;
+    F.a = d_z;
+    F.t = d_t;
+    F.xmapr = d_xm;
+    F.ymapr = d_ym;
+    F.fcoriolis = d_fc;
+    F.out = d_out;
+    F.undef = undef;
+    F.scale = tscale;
+    F.scale2 = cscale;
+    const int r = run_fused2(c, F, fdefined);
+    if (r == 0)
+      return 0;
+    if (r == 1) {
+      if (!fetch_out(c, 5, qcomp, n, memkind))
+        return 0;
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+      return 1;
+    }
+  }
+  if (!ensure_slot(c, 8, n * sizeof(float)) || !ensure_slot(c, 9, n * sizeof(float)))
     return 0;
   float* d_ug = static_cast<float*>(c->slot[8]);
   float* d_vg = static_cast<float*>(c->slot[9]);
@@ -1052,7 +1136,7 @@ int mifc_plevelqvector(mifc_ctx* c, int nx, int ny, const float* z, const float*
   StencilCall pass3 = {compute < 3 ? mifc::ST_QVEC_X : mifc::ST_QVEC_Y, nx, ny, 1, d_ug, d_vg, d_xm, d_ym, nullptr, d_out, nullptr};
   pass3.f2 = d_t;
   pass3.scale = tscale;
-  pass3.scale2 = (float)((double)(-287.f) / ((double)p * 100.)); // :564
+  pass3.scale2 = cscale;
   if (!run_stencil(c, pass3, fdefined, undef, MIFC_MEM_DEVICE))
     return 0;
   if (!fetch_out(c, 5, qcomp, n, memkind))

@@ -229,6 +229,37 @@ struct ShapiroParams
 };
 hipError_t launch_shapiro2(const ShapiroParams& prm, hipStream_t stream);
 
+// Stencil-of-a-stencil operators in one launch (mifc_fused2.hip): the
+// intermediate field(s) of thermalFrontParameter (:2266) and plevelqvector
+// (:505) live in LDS row rings instead of going through HBM.
+enum Fused2Op
+{
+  F2_TFP = 0,    // a = tx
+  F2_QVEC_X = 1, // a = z, t = temperature; compute 1, 2
+  F2_QVEC_Y = 2  // compute 3, 4
+};
+struct Fused2Params
+{
+  int op;
+  int nx, ny;
+  int check; // input flag != ALL_DEFINED
+  const float* a;
+  const float* t;
+  const float* xmapr;
+  const float* ymapr;
+  const float* fcoriolis; // Q-vector only
+  float* out;
+  float undef;
+  float scale;  // Q-vector: tscale
+  float scale2; // Q-vector: c (:564)
+  // [0] cells the first pass left undefined (TFP, tested input only)
+  // [1] cells the last pass left undefined (what the returned flag is made from)
+  // [2] TFP, tested input only: cells of the last pass that only the defined-test rejected
+  u64* counts;
+};
+bool fused2_supported(const Fused2Params& prm);
+hipError_t launch_fused2(const Fused2Params& prm, hipStream_t stream);
+
 // diagnostic: two-in / two-out streaming copy (bandwidth yardstick)
 hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const float* s0, const float* s1, size_t n_floats, hipStream_t stream);
 

@@ -74,6 +74,48 @@ def stencil_cases(grids=GRIDS_STENCIL, modes=MODES):
     return cases
 
 
+def fused2_cases():
+    """thermalFrontParameter / plevelqvector on grids the single-launch kernel takes (nx % 4 == 0):
+    one thread-quad wide, one band, many bands, the headline width; the usual flag modes plus
+    the ones that matter to the pass-to-pass flag logic of the reference (:2286, :664)."""
+    out = []
+    for nx, ny in [(4, 3), (4, 9), (8, 3), (12, 20), (64, 48), (128, 301), (1440, 37)]:
+        xm, ym, fc = synth.grid_maps(nx, ny)
+        seed = 31 * nx + ny
+        z = synth.scalar_field(nx, ny, seed)
+        variants = []
+        for mode in MODES:
+            (z_,), flag = _apply_mode([z], mode, seed, _frac(nx, ny))
+            variants.append((mode, z_, flag, xm))
+        # every value defined, but the caller does not promise it: the first pass of TFP
+        # finds nothing and hands ALL_DEFINED to the second
+        variants.append(("clean-some", z, SOME_DEFINED, xm))
+        # a plateau: |grad| == 0 cells are rejected whatever the flag says (:2292)
+        zp = z.copy()
+        zp[ny // 3:, : max(3, nx // 2)] = np.float32(5432.0)
+        variants.append(("plateau-all", zp, ALL_DEFINED, xm))
+        variants.append(("plateau-some", zp, SOME_DEFINED, xm))
+        if nx >= 8 and ny >= 9:
+            # defined inputs whose gradient is NaN (0 * inf): with a clean first pass the
+            # reference computes with it, a tested second pass would not
+            zn, xn = z.copy(), xm.copy()
+            j, i = ny // 2, nx // 2
+            zn[j, i - 1], zn[j, i + 1] = np.float32(-3.0e38), np.float32(3.0e38)
+            xn[j, i] = np.float32(0.0)
+            variants.append(("nan-gradient-some", zn, SOME_DEFINED, xn))
+            variants.append(("nan-gradient-all", zn, ALL_DEFINED, xn))
+        for name, z_, flag, xm_ in variants:
+            base = dict(nx=nx, ny=ny, fdefined=flag, undef=UNDEF)
+            lab = "%dx%d-%s" % (nx, ny, name)
+            out.append(dict(base, op="thermalFrontParameter", args=[z_, xm_, ym], label="tfp-" + lab))
+            bad = (z_ == UNDEF) | np.isnan(z_)
+            with np.errstate(all="ignore"):
+                tq = np.where(bad, z_, np.float32(250.0) + np.float32(0.05) * (z_ - np.float32(5500.0))).astype(np.float32)
+            for c in (1, 2, 3, 4):
+                out.append(dict(base, op="plevelqvector", args=[z_, tq, xm_, ym, fc, 700.0, c], label="qvector%d-%s" % (c, lab)))
+    return out
+
+
 def ewise_cases(grids=GRIDS_EWISE, modes=MODES):
     cases = []
     for (nx, ny), mode in itertools.product(grids, modes):

@@ -586,3 +586,14 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev):
             if e1 is not None:
                 assert cases.same_bits(o1[l], e1, nan_payload=False), (name, l)
             assert fo[l] == f_e, (name, l, fo[l], f_e)
+
+
+# ------------------------------------------------------------------ fused stencil-of-a-stencil kernels (mifc_fused2.hip)
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("device", [False, True])
+def test_fused_tfp_and_qvector(gpu_ctx, oracle, fused, device, monkeypatch):
+    """One launch with the intermediate fields in LDS == the reference's pass-by-pass result, flags
+    included; MIFC_FUSED2=0 runs the multi-pass path on the same cases."""
+    monkeypatch.setenv("MIFC_FUSED2", fused)
+    for case in cases.fused2_cases():
+        _check_case(gpu_ctx, oracle, case, device=device)

@@ -40,6 +40,15 @@ def test_stencils_bit_exact(oracle, ref):
         _check(oracle, ref, case)
 
 
+def test_two_pass_stencils_bit_exact(oracle, ref):
+    """thermalFrontParameter / plevelqvector where the flag handed from pass to pass matters
+    (clean first pass, zero-gradient plateaus, a NaN gradient from defined inputs)."""
+    cs = cases.fused2_cases()
+    assert len(cs) > 250
+    for case in cs:
+        _check(oracle, ref, case)
+
+
 def test_elementwise_bit_exact(oracle, ref):
     cs = cases.ewise_cases()
     assert len(cs) > 1500

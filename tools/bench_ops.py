@@ -139,9 +139,9 @@ def main():
     add("advection", 24, 0, lambda: ctx.advection(tall(z), tall(u), tall(v), xm_t, ym_t, 1.0, fdefined=ALLD, out=o_t), "advection",
         [h["z"], h["u"], h["v"], xm, ym, 1.0])
     add("jacobian", 20, 0, lambda: ctx.jacobian(tall(z), tall(u), xm_t, ym_t, fdefined=ALLD, out=o_t), "jacobian", [h["z"], h["u"], xm, ym])
-    add("thermalFrontParameter (2 passes)", 16, 0, lambda: ctx.thermalFrontParameter(tall(t), xm_t, ym_t, fdefined=ALLD, out=o_t),
+    add("thermalFrontParameter", 16, 0, lambda: ctx.thermalFrontParameter(tall(t), xm_t, ym_t, fdefined=ALLD, out=o_t),
         "thermalFrontParameter", [h["t"], xm, ym])
-    add("plevelqvector (3 passes)", 24, 0, lambda: ctx.plevelqvector(tall(z), tall(t), xm_t, ym_t, fc_t, 500.0, 1, fdefined=ALLD, out=o_t),
+    add("plevelqvector c=1", 24, 0, lambda: ctx.plevelqvector(tall(z), tall(t), xm_t, ym_t, fc_t, 500.0, 1, fdefined=ALLD, out=o_t),
         "plevelqvector", [h["z"], h["t"], xm, ym, fcor, 500.0, 1])
     # ---- 8f-3: pointwise catalogue
     t2 = (t - 20.0).contiguous()
