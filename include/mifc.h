@@ -332,6 +332,12 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int 
 int mifc_bench_stream2(mifc_ctx* ctx, int variant, int blocks, float* dst0, float* dst1, const float* src0, const float* src1,
                        size_t n_floats);
 
+/* Arithmetic self-check of the fused stencil kernels' division: for i < n writes
+ * (float)((0.5 * a[i] * b[i] * 9.8f) / g[i]) (operands promoted to double) once
+ * through the shared-reciprocal quotient the kernels use and once through a plain
+ * double division; the two must agree bit for bit.  Device pointers, asynchronous. */
+int mifc_diag_division(mifc_ctx* ctx, const float* a, const float* b, const float* g, float* shared, float* plain, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

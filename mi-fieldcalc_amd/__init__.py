@@ -571,6 +571,11 @@ class Context:
         )
         return bool(rc)
 
+    def diag_division(self, a, b, g, shared, plain):
+        """Arithmetic self-check (see include/mifc.h); device tensors of equal length."""
+        self._bind_stream(MEM_DEVICE)
+        return bool(self._call("mifc_diag_division", [a.data_ptr(), b.data_ptr(), g.data_ptr(), shared.data_ptr(), plain.data_ptr(), a.numel()]))
+
     def bench_stream2(self, variant, blocks, dst0, dst1, src0, src1):
         """Bandwidth yardstick (see include/mifc.h); device tensors."""
         self._bind_stream(MEM_DEVICE)

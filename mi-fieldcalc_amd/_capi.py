@@ -132,6 +132,7 @@ SIGNATURES = {
     "mifc_vortdiv_slab_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu"]),
     # diagnostics
     "mifc_bench_stream2": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "z"]),
+    "mifc_diag_division": ("i", ["ctx", "p", "p", "p", "p", "p", "z"]),
 }
 
 

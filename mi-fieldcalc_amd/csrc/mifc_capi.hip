@@ -1491,4 +1491,13 @@ int mifc_bench_stream2(mifc_ctx* c, int variant, int blocks, float* dst0, float*
   return 1;
 }
 
+int mifc_diag_division(mifc_ctx* c, const float* a, const float* b, const float* g, float* shared, float* plain, size_t n)
+{
+  if (!c)
+    return 0;
+  enter(c);
+  MIFC_HIP(c, mifc::launch_division_check(a, b, g, shared, plain, n, c->stream));
+  return 1;
+}
+
 } // extern "C"

@@ -332,6 +332,29 @@ __device__ __forceinline__ float f_diverg(float xm, float ym, float dudx, float 
 }
 #endif
 
+// ---- two double quotients with one denominator
+// The compiler expands a / b (f64) into v_div_scale x2, v_rcp_f64, four Newton fmas, then
+// q = a*y, r = fma(-b, q, a), v_div_fmas(r, y, q), v_div_fixup (LLVM AMDGPU LowerFDIV64).
+// v_div_scale only rescales operands near the ends of the double range (denormal b, 1/b or
+// a/b, |a| < 2^-969, exponents >= 768 apart); values converted from float, and products of
+// two or three of them, never get there, so for those the sequence below IS that expansion,
+// bit for bit -- and quotients that share b share the v_rcp_f64 and the four fmas.
+// Zero, infinite and NaN operands are settled by v_div_fixup as in the expansion.
+__device__ __forceinline__ double shared_reciprocal(double b)
+{
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double quotient(double a, double b, double y /* shared_reciprocal(b) */)
+{
+  const double q = a * y;
+  const double r = __builtin_fma(-b, q, a);
+  return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q), b, a);
+}
+
 // ---- undefined-cell counting: one atomic per wave, none when nothing to add
 __device__ __forceinline__ void wave_count_add(u64* counter, unsigned int my_count)
 {

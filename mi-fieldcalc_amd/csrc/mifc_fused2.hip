@@ -179,8 +179,9 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
         for (int k = 0; k < 4; ++k) {
           const float s = sv[k], n = nv[k], w = cv[k], e = cv[k + 2];
           const bool ok = is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef);
-          const float u = (float)(-0.5 * (double)ym[k] * (double)(n - s) * (double)MIFC_K_G / (double)fc[k]);
-          const float v = (float)(0.5 * (double)xm[k] * (double)(e - w) * (double)MIFC_K_G / (double)fc[k]);
+          const double fd = (double)fc[k], finv = shared_reciprocal(fd);
+          const float u = (float)quotient(-0.5 * (double)ym[k] * (double)(n - s) * (double)MIFC_K_G, fd, finv);
+          const float v = (float)quotient(0.5 * (double)xm[k] * (double)(e - w) * (double)MIFC_K_G, fd, finv);
           ug[k] = (!CHECK || ok) ? u : undef;
           vg[k] = ok ? v : undef;
         }
@@ -231,8 +232,9 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
           const double hx = 0.5 * (double)xm[k], hy = 0.5 * (double)ym[k];
           const float dabsdeltdx = (float)(hx * (double)(gc[k + 2] - gc[k]));
           const float dabsdeltdy = (float)(hy * (double)(gn[k] - gs[k]));
-          const float dtdxa = (float)(hx * (double)(tc[k + 2] - tc[k]) / (double)g);
-          const float dtdya = (float)(hy * (double)(tn[k] - ts[k]) / (double)g);
+          const double gd = (double)g, ginv = shared_reciprocal(gd);
+          const float dtdxa = (float)quotient(hx * (double)(tc[k + 2] - tc[k]), gd, ginv);
+          const float dtdya = (float)quotient(hy * (double)(tn[k] - ts[k]), gd, ginv);
           o[k] = ok ? -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya) : undef;
           n2 += ok ? 0u : 1u;
           if (CHECK && !def && g != 0)
@@ -303,6 +305,16 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
   wave_count_add(P.counts + 1, n2);
 }
 
+// diagnostic: the same quotient through shared_reciprocal()/quotient() and through the compiler's a / b
+__global__ void division_check_kernel(const float* a, const float* b, const float* g, float* shared, float* plain, size_t n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const double num = 0.5 * (double)a[i] * (double)b[i] * (double)MIFC_K_G, den = (double)g[i];
+    shared[i] = (float)quotient(num, den, shared_reciprocal(den));
+    plain[i] = (float)(num / den);
+  }
+}
+
 size_t lds_bytes(const Fused2Params& p)
 {
   const size_t rows = p.op == F2_TFP ? 5 + 3 : 3 + 3 + 3 + 3;
@@ -353,6 +365,12 @@ bool aligned16(const void* p)
 }
 
 } // namespace
+
+hipError_t launch_division_check(const float* a, const float* b, const float* g, float* shared, float* plain, size_t n, hipStream_t stream)
+{
+  hipLaunchKernelGGL(division_check_kernel, dim3(1024), dim3(256), 0, stream, a, b, g, shared, plain, n);
+  return hipGetLastError();
+}
 
 bool fused2_supported(const Fused2Params& p)
 {

@@ -597,3 +597,31 @@ def test_fused_tfp_and_qvector(gpu_ctx, oracle, fused, device, monkeypatch):
     monkeypatch.setenv("MIFC_FUSED2", fused)
     for case in cases.fused2_cases():
         _check_case(gpu_ctx, oracle, case, device=device)
+
+
+def test_shared_reciprocal_division_is_the_plain_division(gpu_ctx):
+    """The fused kernels divide two numerators by one denominator through one refined reciprocal
+    (csrc/mifc_device.h); for float-born operands that must be the f64 division, bit for bit --
+    including zeros, infinities, NaNs, denormals and the ends of the float range."""
+    import torch
+
+    n = 1 << 22
+    gen = torch.Generator().manual_seed(2024)
+    bits = lambda: torch.randint(-(2 ** 31), 2 ** 31 - 1, (n,), generator=gen, dtype=torch.int64).to(torch.int32).view(torch.float32)
+    special = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 1e-45, -1e-45, 1.17549435e-38, 3.4028235e38, -3.4028235e38,
+                            1.0, -1.0, 3.0, 1e35, 9.8, 1e-5, 2.5e-5, 1.4e-4], dtype=torch.float32)
+    ops = []
+    for k in range(3):
+        x = bits()  # every bit pattern is a float: all exponents, denormals, NaNs
+        ordinary = (torch.rand(n, generator=gen) * 200 - 100) * 10 ** torch.randint(-6, 6, (n,), generator=gen).float()
+        x = torch.where(torch.rand(n, generator=gen) < 0.5, x, ordinary)
+        x[: special.numel() ** 2] = special.repeat_interleave(special.numel()) if k == 0 else special.repeat(special.numel())
+        ops.append(x.cuda())
+    ops[1][: special.numel() ** 2] = 1.0
+    shared = torch.empty(n, device="cuda")
+    plain = torch.empty(n, device="cuda")
+    assert gpu_ctx.diag_division(ops[0], ops[1], ops[2], shared, plain)
+    torch.cuda.synchronize()
+    s, p = shared.cpu().numpy(), plain.cpu().numpy()
+    assert cases.same_bits(s, p, nan_payload=False)
+    assert np.isfinite(p).sum() > n // 4  # the sweep is not all overflow
