@@ -82,8 +82,8 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
   const int nx = P.nx, ny = P.ny;
   const int S = nx + 2 * F2_PAD;
   float* ringA = reinterpret_cast<float*>(lds4) + F2_PAD; // source rows: tx | z
-  float* ringT = ringA + RA * S;                          // Q-vector: temperature rows (3)
-  float* mid0 = ringT + (TFP ? 0 : 3 * S);                // |grad tx| | ug, filled (3)
+  float* ringT = ringA + RA * S;                          // Q-vector: temperature rows (4)
+  float* mid0 = ringT + (TFP ? 0 : 4 * S);                // |grad tx| | ug, filled (3)
   float* mid1 = mid0 + 3 * S;                             // Q-vector: vg, filled (3)
 
   const int c = threadIdx.x;
@@ -99,43 +99,43 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
   const int rs = jb0 - 2, re = jb1 + 1;
 
   const size_t col = (size_t)x0;
-  float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pt = pa, pxm = pa, pym = pa, pfc = pa; // prefetched: A(r), t(r-1), maps(r-1)
-  float4 xm_o = pa, ym_o = pa;                                                          // maps of the row stage B works on
-  if (active) {
-    if (rs >= 0)
-      pa = ld4(P.a + (size_t)rs * nx + col);
-    if (rs - 1 >= 0) {
-      pxm = ld4(P.xmapr + (size_t)(rs - 1) * nx + col);
-      pym = ld4(P.ymapr + (size_t)(rs - 1) * nx + col);
-      if (!TFP) {
-        pfc = ld4(P.fcoriolis + (size_t)(rs - 1) * nx + col);
-        pt = ld4(P.t + (size_t)(rs - 1) * nx + col);
-      }
-    }
-  }
+  const size_t ccol = active ? col : 0; // lanes beyond the row width load column 0 and use nothing
+  if (active && rs >= 0)
+    *reinterpret_cast<float4*>(ringA + (rs % RA) * S + x0) = ld4(P.a + (size_t)rs * nx + col);
   unsigned int n1 = 0, n2 = 0, n2c = 0;
 
+  // Map-factor rows live in registers from the iteration that loads them (r) through stage A
+  // (r+1) to stage B (r+2): three sets, rotated by unrolling the row loop three times.
+  struct RowMaps
+  {
+    float4 xm, ym, fc;
+  };
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  RowMaps m0 = {zero4, zero4, zero4}, m1 = m0, m2 = m0;
+
+  // One iteration.  Global loads are issued at the top and land in LDS at the end, just before
+  // the result row is stored: the wait there covers loads only (the previous store is a whole
+  // iteration old), and the store gets the next iteration to drain.
   // LDS hazards, with the two barriers per iteration:
-  //   ring A, TFP (5): row r written at the top replaces row r-5, last read by stage B of iteration r-2
-  //   ring A, Q-vector (3): replaces row r-3, last read by stage A of iteration r-1 (before that iteration's second barrier)
-  //   ring M / ring T (3): row r-1 written in stage A replaces row r-4, last read by stage B of iteration r-1 (before this iteration's first barrier)
-  for (int r = rs; r <= re; ++r) {
-    const float4 xm_g = pxm, ym_g = pym, fc_g = pfc, t_w = pt; // maps / temperature of row r-1
-    if (active) {
-      if (r >= 0 && r < ny)
-        *reinterpret_cast<float4*>(ringA + (r % RA) * S + x0) = pa;
-      if (r < re) {
-        if (r + 1 >= 0 && r + 1 < ny)
-          pa = ld4(P.a + (size_t)(r + 1) * nx + col);
-        if (r >= 0 && r < ny) {
-          pxm = ld4(P.xmapr + (size_t)r * nx + col);
-          pym = ld4(P.ymapr + (size_t)r * nx + col);
-          if (!TFP) {
-            pfc = ld4(P.fcoriolis + (size_t)r * nx + col);
-            pt = ld4(P.t + (size_t)r * nx + col);
-          }
-        }
-      }
+  //   ring A, TFP (5): row r+1 written at the end replaces row r-4, last read by stage B of iteration r-1
+  //   ring A, Q-vector (3): replaces row r-2, last read by stage A of this iteration (before its second barrier)
+  //   ring T (4): row r written at the end replaces row r-4, last read by stage B of iteration r-1
+  //   ring M (3): row r-1 written in stage A replaces row r-4, last read by stage B of iteration r-1 (before this iteration's first barrier)
+  auto iteration = [&](const int r, RowMaps& m_new /* row r */, const RowMaps& m_a /* row r-1 */, const RowMaps& m_b /* row r-2 */)
+                       __attribute__((always_inline)) {
+    // Unconditional loads (row and column clamped into the field): a load under a condition
+    // would make the compiler merge old and new register contents right here, i.e. wait for it.
+    const bool load_a = r < re && r + 1 >= 0 && r + 1 < ny;
+    const bool load_row = r < re && r >= 0 && r < ny;
+    const size_t row_a = (size_t)(r + 1 < 0 ? 0 : (r + 1 > ny - 1 ? ny - 1 : r + 1)) * nx + ccol;
+    const size_t row_m = (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + ccol;
+    const float4 pa = ld4(P.a + row_a); // in flight: A(r+1), t(r), maps(r)
+    float4 pt = zero4;
+    m_new.xm = ld4(P.xmapr + row_m);
+    m_new.ym = ld4(P.ymapr + row_m);
+    if (!TFP) {
+      m_new.fc = ld4(P.fcoriolis + row_m);
+      pt = ld4(P.t + row_m);
     }
     lds_barrier();
 
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
       unpack(ld4(Sr + x0), sv);
       unpack(ld4(Nr + x0), nv);
       row6(Sr, Cr, Nr, x0, nx, first, last, cv);
-      unpack(xm_g, xm);
-      unpack(ym_g, ym);
+      unpack(m_a.xm, xm);
+      unpack(m_a.ym, ym);
       if (TFP) {
         // gradient compute 3, :2037-2046
         const bool counted = CHECK && y >= jb0 && y < jb1; // every row is counted by the band that owns it
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
         // plevelgwind_xcomp :660-663 (tests only if the caller's flag is not ALL_DEFINED),
         // plevelgwind_ycomp :693-698 (always tests: the x pass hands it NONE_DEFINED, :664)
         float fc[4], ug[4], vg[4];
-        unpack(fc_g, fc);
+        unpack(m_a.fc, fc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float s = sv[k], n = nv[k], w = cv[k], e = cv[k + 2];
@@ -197,17 +197,17 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
         st4(mid1 + (y % 3) * S + x0, vg);
       }
     }
-    if (!TFP && active && y >= 0 && y < ny)
-      *reinterpret_cast<float4*>(ringT + (y % 3) * S + x0) = t_w;
     lds_barrier();
 
     // ---- stage B: result row j = r-2
     const int j = r - 2;
-    if (active && j >= jb0 && j < jb1) {
+    const bool have_row = active && j >= jb0 && j < jb1;
+    float o[4] = {undef, undef, undef, undef};
+    if (have_row) {
       const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > ny - 2) ? ny - 2 : j + 1; // filled intermediate rows 0 / ny-1 are rows 1 / ny-2
-      float xm[4], ym[4], o[4];
-      unpack(xm_o, xm);
-      unpack(ym_o, ym);
+      float xm[4], ym[4];
+      unpack(m_b.xm, xm);
+      unpack(m_b.ym, ym);
       if (TFP) {
         const float* Gs = mid0 + (js % 3) * S;
         const float* Gc = mid0 + (j % 3) * S;
@@ -247,9 +247,9 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
         const float* Vs = mid1 + (js % 3) * S;
         const float* Vc = mid1 + (j % 3) * S;
         const float* Vn = mid1 + (jn % 3) * S;
-        const float* Ts = ringT + ((j - 1) % 3) * S;
-        const float* Tc = ringT + (j % 3) * S;
-        const float* Tn = ringT + ((j + 1) % 3) * S;
+        const float* Ts = ringT + ((j - 1) % 4) * S;
+        const float* Tc = ringT + (j % 4) * S;
+        const float* Tn = ringT + ((j + 1) % 4) * S;
         float us[4], un[4], uc[6], vs[4], vn[4], vc[6], ts[4], tn[4], tc[6];
         unpack(ld4(Us + x0), us);
         unpack(ld4(Un + x0), un);
@@ -287,6 +287,17 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
         o[0] = o[1];
       if (last)
         o[3] = o[2];
+    }
+    // rows that were in flight since the top of the iteration; the explicit vmcnt(0) (all paths,
+    // loads only by now) keeps the compiler from waiting again -- behind the store -- at the loop edge
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (active) {
+      if (load_a)
+        *reinterpret_cast<float4*>(ringA + ((r + 1) % RA) * S + x0) = pa;
+      if (!TFP && load_row)
+        *reinterpret_cast<float4*>(ringT + (r % 4) * S + x0) = pt;
+    }
+    if (have_row) {
       // the result is written once and never re-read here: nontemporal
       const v4f q = {o[0], o[1], o[2], o[3]};
       __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)j * nx + col));
@@ -295,8 +306,15 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
       if (j == ny - 2)
         __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)(ny - 1) * nx + col));
     }
-    xm_o = xm_g;
-    ym_o = ym_g;
+  };
+  for (int r = rs; r <= re; r += 3) {
+    iteration(r, m0, m2, m1);
+    if (r + 1 > re)
+      break;
+    iteration(r + 1, m1, m0, m2);
+    if (r + 2 > re)
+      break;
+    iteration(r + 2, m2, m1, m0);
   }
   if (TFP && CHECK) {
     wave_count_add(P.counts + 0, n1);
@@ -317,7 +335,7 @@ __global__ void division_check_kernel(const float* a, const float* b, const floa
 
 size_t lds_bytes(const Fused2Params& p)
 {
-  const size_t rows = p.op == F2_TFP ? 5 + 3 : 3 + 3 + 3 + 3;
+  const size_t rows = p.op == F2_TFP ? 5 + 3 : 3 + 4 + 3 + 3;
   return rows * (size_t)(p.nx + 2 * F2_PAD) * sizeof(float);
 }
 
