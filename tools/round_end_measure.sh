@@ -14,6 +14,10 @@ bash tools/profile_gpu.sh "$TAG" > gpurun_out/profile_gpu.log 2>&1
 echo "profile rc=$?"; tail -25 gpurun_out/profile_gpu.log
 python3 tools/bench_ops.py 137 > gpurun_out/per_operator_table.txt 2>&1
 echo "ops rc=$?"
+# the two stencil-of-a-stencil operators: one fused launch vs the multi-pass path, same box
+{ echo "# fused (default)"; BENCH_OPS_ONLY="thermalFront|qvector" python3 tools/bench_ops.py 137 | tail -n 3;
+  echo "# MIFC_FUSED2=0 (multi-pass)"; MIFC_FUSED2=0 BENCH_OPS_ONLY="thermalFront|qvector" python3 tools/bench_ops.py 137 | tail -n 3; } > gpurun_out/fused2_ops.txt 2>&1
+echo "fused2 rc=$?"
 python3 tools/bench_hostpath.py > gpurun_out/hostpath_after.jsonl 2>&1
 echo "hostpath rc=$?"
 python3 tools/bench_configs.py > gpurun_out/other_configs.jsonl 2>&1
