@@ -79,7 +79,8 @@ def fused2_cases():
     one thread-quad wide, one band, many bands, the headline width; the usual flag modes plus
     the ones that matter to the pass-to-pass flag logic of the reference (:2286, :664)."""
     out = []
-    for nx, ny in [(4, 3), (4, 9), (8, 3), (12, 20), (64, 48), (128, 301), (1440, 37)]:
+    # ... and the widest rows the kernel takes: 1024 lanes (TFP), LDS-limited 3140 (Q-vector; 3144 falls back)
+    for nx, ny in [(4, 3), (4, 9), (8, 3), (12, 20), (64, 48), (128, 301), (1440, 37), (4096, 6), (3140, 11), (3144, 5)]:
         xm, ym, fc = synth.grid_maps(nx, ny)
         seed = 31 * nx + ny
         z = synth.scalar_field(nx, ny, seed)
