@@ -328,7 +328,9 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int 
  * device pointers, 16-byte aligned, n_floats % 4 == 0) with the operators'
  * access shape and no arithmetic.  variant 0: plain loads/stores, 1: nontemporal
  * stores, 2: nontemporal loads and stores.  blocks <= 0: one lane per 16 bytes;
- * otherwise a grid-stride loop over `blocks` workgroups of 256.  Asynchronous. */
+ * otherwise a grid-stride loop over `blocks` workgroups of 256.  variant 3:
+ * split-role copy (waves either load or store); variant 4: `blocks` workgroups
+ * of 384 lanes, each streaming one contiguous chunk front to back.  Asynchronous. */
 int mifc_bench_stream2(mifc_ctx* ctx, int variant, int blocks, float* dst0, float* dst1, const float* src0, const float* src1,
                        size_t n_floats);
 

@@ -525,6 +525,34 @@ __global__ __launch_bounds__(512) void stream2_split_kernel(float* __restrict__ 
       put(tile + step, 1);
   }
 }
+// Variant 4: a LOOP copy in which every workgroup streams ONE contiguous chunk of
+// each array front to back (384 lanes = one 1440-column row per step, next step
+// prefetched): the memory access shape of a kernel whose workgroups span the
+// whole row width and walk down a band of rows.
+__global__ __launch_bounds__(384) void stream2_band_kernel(float* __restrict__ d0, float* __restrict__ d1, const float* __restrict__ s0,
+                                                           const float* __restrict__ s1, size_t n4, size_t chunk)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f* a = reinterpret_cast<const v4f*>(s0);
+  const v4f* b = reinterpret_cast<const v4f*>(s1);
+  v4f* x = reinterpret_cast<v4f*>(d0);
+  v4f* y = reinterpret_cast<v4f*>(d1);
+  const size_t beg = (size_t)blockIdx.x * chunk;
+  if (beg >= n4)
+    return;
+  const size_t end = beg + chunk < n4 ? beg + chunk : n4;
+  size_t q = beg + threadIdx.x;
+  size_t qc = q < end ? q : end - 1; // loads are unconditional (clamped), see mifc_fused2.hip
+  v4f pa = a[qc], pb = b[qc];
+  for (; q < end; q += 384) {
+    const v4f va = pa, vb = pb;
+    const size_t qn = q + 384 < end ? q + 384 : end - 1;
+    pa = a[qn];
+    pb = b[qn];
+    __builtin_nontemporal_store(va, x + q);
+    __builtin_nontemporal_store(vb, y + q);
+  }
+}
 } // namespace
 
 hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const float* s0, const float* s1, size_t n_floats, hipStream_t stream)
@@ -535,6 +563,9 @@ hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const f
     blocks = (int)(want > 0x7fffffff ? 0x7fffffff : want);
   }
   switch (variant) {
+  case 4:
+    hipLaunchKernelGGL(stream2_band_kernel, dim3(blocks), dim3(384), 0, stream, d0, d1, s0, s1, n4, (n4 + (size_t)blocks - 1) / (size_t)blocks);
+    break;
   case 3:
     hipLaunchKernelGGL(stream2_split_kernel, dim3(blocks), dim3(512), 0, stream, d0, d1, s0, s1, n4);
     break;

@@ -12,11 +12,12 @@
 // row rings, so every field is read from HBM once (plus the band's halo rows)
 // and only the result is written:
 //
-//   iteration r:  top      source row r (prefetched into registers one
-//                          iteration earlier) -> ring A; prefetch row r+1
+//   iteration r:  top      issue the global loads of source row r+1 and of
+//                          map-factor row r (registers)
 //                 stage A  intermediate row r-1 from source rows r-2..r -> ring M
 //                 stage B  result row r-2 from intermediate rows r-3..r-1
 //                          (and source/temperature rows r-3..r-1)
+//                 end      the loaded source row lands in ring A; store row r-2
 //
 // Reference semantics kept (mifc_stencil.hip header): every pass is a flat loop
 // over rows 1..ny-2 whose edge-column cells see neighbours wrapped into the

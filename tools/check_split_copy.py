@@ -9,3 +9,11 @@ for n in (1440*720*3, 1000*4+ 4*77, 256*4*4096*2 + 4*5):
         torch.cuda.synchronize()
         assert torch.equal(x, a) and torch.equal(y, b), (n, blocks)
 print("split-role copy correct")
+for n in (1440*720*3, 1000*4 + 4*77, 384*4*50 + 4*5):
+    a = torch.randn(n, device='cuda'); b = torch.randn(n, device='cuda')
+    for blocks in (1, 7, 1024):
+        x = torch.zeros_like(a); y = torch.zeros_like(b)
+        assert ctx.bench_stream2(4, blocks, x, y, a, b)
+        torch.cuda.synchronize()
+        assert torch.equal(x, a) and torch.equal(y, b), (n, blocks)
+print("band copy correct")

@@ -33,6 +33,11 @@ YARD = {
     "split-role loop copy, 2048 blk": (3, 2048),
     "split-role loop copy, 4096 blk": (3, 4096),
     "split-role copy, 1 tile pair/blk": (3, 0),
+    # every workgroup streams one contiguous chunk (row-wide workgroups walking down a band of rows)
+    "band copy, 64-row chunks": (4, 1542),
+    "band copy, 32-row chunks": (4, 3083),
+    "band copy, 16-row chunks": (4, 6165),
+    "band copy, 8-row chunks": (4, 12330),
 }
 
 
