@@ -521,9 +521,142 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
     wave_count_add(P.n_undefined + lev, bad);
 }
 
+// ---------------------------------------------------------------------------
+// One-shot form with the row reuse in LDS (tuning K=2): a workgroup is RB+2
+// waves = RB+2 consecutive rows x 256 columns of one level.  Every wave loads
+// ITS row once (u, v, map factors, one edge scalar), parks u and v in LDS,
+// and after one barrier the RB inner waves take the rows above and below from
+// there.  Loads per cell: (RB+2)/RB instead of the 3 of K=1, no row loop.
+template <bool CHECK, bool WANT_V, bool WANT_D, bool NT, int RB>
+__global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsParams P)
+{
+  __shared__ v4f su[RB + 2][64];
+  __shared__ v4f sv[RB + 2][64];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int bid = blockIdx.x;
+  const int seq = P.xcd_remap ? ((bid & 7) * P.per_xcd + (bid >> 3)) : bid;
+  if (seq >= P.n_logical)
+    return;
+  // address order: column segment fastest, then row block, then level
+  const int per_level = P.uB * P.uW;
+  const int lev = seq / per_level;
+  const int rem = seq - lev * per_level;
+  const int rblock = rem / P.uW;
+  const int wc = rem - rblock * P.uW;
+
+  const int nx = P.nx;
+  // wave 0 and wave RB+1 hold the halo rows; rows past the computed range are only loaded (clamped to the
+  // row after the last computed one, which always exists) for the neighbour below them
+  const int jl_raw = P.lo + rblock * RB + wave - 1;
+  const int jl = jl_raw > P.hi ? P.hi : jl_raw;
+  const bool computes = wave >= 1 && wave <= RB && jl_raw < P.hi;
+  const int j = P.j0 + jl;
+  const int col = wc * 256 + lane * 4;
+  const bool act = col < nx;
+  const int col_c = act ? col : nx - 4;
+  int east_col = wc * 256 + 256;
+  if (east_col > nx)
+    east_col = nx;
+  const int edge_col = (lane == 63) ? east_col : (wc * 256 - 1);
+  const float undef = P.undef;
+  const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
+
+  const float* __restrict__ u = P.u + (size_t)lev * P.in_stride;
+  const float* __restrict__ v = P.v + (size_t)lev * P.in_stride;
+  const long base = (long)jl * nx;
+  const long o = base + col_c;
+  const v4f uc = load4(u + o), vc = load4(v + o);
+  v4f xm4 = uc, ym4 = uc;
+  float eu = 0.f, ev = 0.f;
+  if (computes) {
+    xm4 = load4(P.xm + o);
+    ym4 = load4(P.ym + o);
+    long e = base + edge_col;
+    e = e < P.idx_lo ? P.idx_lo : (e > P.idx_hi ? P.idx_hi : e);
+    eu = u[e];
+    ev = v[e];
+  }
+  su[wave][lane] = uc;
+  sv[wave][lane] = vc;
+  __syncthreads();
+  if (!computes)
+    return;
+  const v4f un = su[wave + 1][lane], us = su[wave - 1][lane];
+  const v4f vn = sv[wave + 1][lane], vs = sv[wave - 1][lane];
+
+  const float east_u = readlane_f(eu, 63), east_v = readlane_f(ev, 63);
+  float uW = dpp_from_lower_lane(eu, uc.w), vW = dpp_from_lower_lane(ev, vc.w);
+  float uE = dpp_from_upper_lane(eu, uc.x), vE = dpp_from_upper_lane(ev, vc.x);
+  if (col + 4 >= east_col) {
+    uE = east_u;
+    vE = east_v;
+  }
+  const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
+  const float vcx[6] = {vW, vc.x, vc.y, vc.z, vc.w, vE};
+  float zv[4], zd[4];
+  unsigned int bad = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float vw = vcx[k], ve = vcx[k + 2], uw = ucx[k], ue = ucx[k + 2];
+    bool ok = true;
+    if (CHECK)
+      ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef)); // :1861, :1927
+    zv[k] = 0.f;
+    zd[k] = 0.f;
+    if (WANT_V)
+      zv[k] = ok ? f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]) : undef;
+    if (WANT_D)
+      zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]) : undef;
+    if (CHECK && !ok && act)
+      bad += 1;
+  }
+  if (col == 0) { // fillEdges, column part (:65-68)
+    zv[0] = zv[1];
+    zd[0] = zd[1];
+  }
+  if (col + 4 == nx) {
+    zv[3] = zv[2];
+    zd[3] = zd[2];
+  }
+  if (act) {
+    const bool top = (j == 1) && (P.j0 == 0);
+    const bool bottom = (j == P.nyg - 2) && (P.j0 + P.ny_local == P.nyg);
+    const long oo = base + col;
+    if (WANT_V) {
+      float* rv = P.rv + (size_t)lev * P.out_stride;
+      v4f z4;
+      z4.x = zv[0];
+      z4.y = zv[1];
+      z4.z = zv[2];
+      z4.w = zv[3];
+      store4<NT>(rv + oo, z4);
+      if (top) // fillEdges, row part (:70-73)
+        store4<NT>(rv + oo - nx, z4);
+      if (bottom)
+        store4<NT>(rv + oo + nx, z4);
+    }
+    if (WANT_D) {
+      float* dv = P.dv + (size_t)lev * P.out_stride;
+      v4f d4;
+      d4.x = zd[0];
+      d4.y = zd[1];
+      d4.z = zd[2];
+      d4.w = zd[3];
+      store4<NT>(dv + oo, d4);
+      if (top)
+        store4<NT>(dv + oo - nx, d4);
+      if (bottom)
+        store4<NT>(dv + oo + nx, d4);
+    }
+  }
+  if (CHECK && P.n_undefined)
+    wave_count_add(P.n_undefined + lev, bad);
+}
+
 struct Tuning
 {
-  int K;     // 0: row-walking kernel (default), 1: one-shot kernel
+  int K;     // 0: row-walking kernel (default), 1: one-shot kernel, 2: one-shot tiles with the row reuse in LDS
   int R;     // rows per band
   int D;     // rows kept in flight beyond the 3-row window (0 or 1)
   int NT;    // nontemporal stores
@@ -773,6 +906,38 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       default:
         ONESHOT(true, true, true);
 #undef ONESHOT
+      }
+      return hipGetLastError();
+    }
+  }
+  if (t.K == 2 && !rp.fc && prm.op != ST_JACOBIAN) { // one-shot tiles: units are (level, block of 8 rows, 256-column segment)
+    constexpr int RB = 8;
+    rp.uB = (rp.hi - rp.lo + RB - 1) / RB;
+    rp.uW = (nx + 255) / 256;
+    const long units = (long)prm.nlev * rp.uB * rp.uW;
+    if (units <= 0x3fffffffL) {
+      rp.n_logical = (int)units;
+      rp.per_xcd = (rp.n_logical + 7) / 8;
+      grid = rp.per_xcd * 8;
+      const bool chk = !prm.every_level_all_defined;
+      const int sel = (chk ? 4 : 0) | (rv ? 2 : 0) | (dv ? 1 : 0);
+      switch (sel) {
+#define TILE(C, WV, WD) \
+  hipLaunchKernelGGL((vortdiv_tile_kernel<C, WV, WD, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp); \
+  break
+      case 1:
+        TILE(false, false, true);
+      case 2:
+        TILE(false, true, false);
+      case 3:
+        TILE(false, true, true);
+      case 5:
+        TILE(true, false, true);
+      case 6:
+        TILE(true, true, false);
+      default:
+        TILE(true, true, true);
+#undef TILE
       }
       return hipGetLastError();
     }

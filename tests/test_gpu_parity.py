@@ -292,7 +292,7 @@ def _expect_levels(oracle, u, v, xm, ym, flags):
 
 
 @pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 9), (516, 70, 6), (260, 11, 5), (17, 9, 7), (1440, 75, 5)])
-@pytest.mark.parametrize("tune", ["", "R=7,D=0", "R=5,D=1,NT=1", "R=64,D=1,WPB=8", "K=1", "K=1,XCD=0,NT=0"])
+@pytest.mark.parametrize("tune", ["", "R=7,D=0", "R=5,D=1,NT=1", "R=64,D=1,WPB=8", "K=1", "K=1,XCD=0,NT=0", "K=2", "K=2,XCD=0"])
 def test_vortdiv_levels_matches_per_level_reference_calls(gpu_ctx, oracle, nx, ny, nlev, tune, monkeypatch):
     import torch
 
