@@ -274,15 +274,17 @@ int mifc_vortdiv_levels_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, const f
  * op selects the reference function:
  *   MIFC_OP_RELVORT .cc:1843, _ABSVORT :1875, _DIVERGENCE :1910, _VORTDIV (both),
  *   MIFC_OP_GRADIENT_X/_Y/_ABS/_LAPLACE = gradient compute 1..4 :1985,
- *   MIFC_OP_GWIND_X :638, _GWIND_Y :674, _GVORT :708, MIFC_OP_IGWIND :1511 (two outputs).
- * f0 = u | z | field | mpot, f1 = v (wind operators only); fcoriolis where the
+ *   MIFC_OP_GWIND_X :638, _GWIND_Y :674, _GVORT :708, MIFC_OP_IGWIND :1511 (two outputs),
+ *   MIFC_OP_JACOBIAN :2424 (f0 = field1, f1 = field2).
+ * f0 = u | z | field | mpot, f1 = v (wind operators and the Jacobian); fcoriolis where the
  * operator takes it, else NULL; out1 only for _VORTDIV / _IGWIND.  f0, f1, out0,
  * out1 : [nlev][ny][nx]; xmapr, ymapr, fcoriolis : [ny][nx] shared.
  * fdefined : host int[nlev] in/out, per level exactly as the single-field call. */
 enum {
   MIFC_OP_RELVORT = 0, MIFC_OP_ABSVORT = 1, MIFC_OP_DIVERGENCE = 2, MIFC_OP_VORTDIV = 3,
   MIFC_OP_GRADIENT_X = 4, MIFC_OP_GRADIENT_Y = 5, MIFC_OP_GRADIENT_ABS = 6, MIFC_OP_GRADIENT_LAPLACE = 7,
-  MIFC_OP_GWIND_X = 8, MIFC_OP_GWIND_Y = 9, MIFC_OP_GVORT = 10, MIFC_OP_IGWIND = 11
+  MIFC_OP_GWIND_X = 8, MIFC_OP_GWIND_Y = 9, MIFC_OP_GVORT = 10, MIFC_OP_IGWIND = 11,
+  MIFC_OP_JACOBIAN = 13
 };
 int mifc_stencil_levels(mifc_ctx* ctx, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* xmapr, const float* ymapr,
                         const float* fcoriolis, float* out0, float* out1, int* fdefined, float undef, int memkind);

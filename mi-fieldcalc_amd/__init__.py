@@ -466,7 +466,7 @@ class Context:
         return outs, flags
 
     OPS = {"relvort": 0, "absvort": 1, "divergence": 2, "vortdiv": 3, "gradient1": 4, "gradient2": 5, "gradient3": 6, "gradient4": 7,
-           "plevelgwind_xcomp": 8, "plevelgwind_ycomp": 9, "plevelgvort": 10, "ilevelgwind": 11}
+           "plevelgwind_xcomp": 8, "plevelgwind_ycomp": 9, "plevelgvort": 10, "ilevelgwind": 11, "jacobian": 13}
 
     def stencil_levels(self, op, f0, f1, xmapr, ymapr, fcoriolis=None, fdefined=None, undef=UNDEF, out0=None, out1=None):
         """Any stencil operator (name from Context.OPS) over f0/f1 of shape (nlev, ny, nx).

@@ -1163,9 +1163,9 @@ int mifc_stencil_levels(mifc_ctx* c, int op, int nx, int ny, int nlev, const flo
   if (!c)
     return 0;
   enter(c);
-  if (op < mifc::ST_RELVORT || op > mifc::ST_IGWIND || !f0 || !out0)
+  if (!((op >= mifc::ST_RELVORT && op <= mifc::ST_IGWIND) || op == mifc::ST_JACOBIAN) || !f0 || !out0)
     return 0;
-  const bool wind = (op <= mifc::ST_VORTDIV);
+  const bool wind = (op <= mifc::ST_VORTDIV) || op == mifc::ST_JACOBIAN; // two input fields per level
   if (wind && !f1)
     return 0;
   const bool two_out = (op == mifc::ST_VORTDIV || op == mifc::ST_IGWIND);

@@ -569,6 +569,7 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev):
         ("gradient3", "gradient", z, None, False, 3, []), ("gradient4", "gradient", z, None, False, 4, []),
         ("plevelgwind_xcomp", "plevelgwind_xcomp", z, None, True, None, []), ("plevelgwind_ycomp", "plevelgwind_ycomp", z, None, True, None, []),
         ("plevelgvort", "plevelgvort", z, None, True, None, []), ("ilevelgwind", "ilevelgwind", z, None, True, None, []),
+        ("jacobian", "jacobian", z, u, False, None, []),
     ]
     for name, cpu_op, f0, f1, use_fc, compute, _ in table:
         res = gpu_ctx.stencil_levels(name, f0, f1, xm, ym, fcor if use_fc else None, fdefined=flags)

@@ -138,7 +138,9 @@ def main():
     ALLD = fc.ALL_DEFINED
     add("advection", 24, 0, lambda: ctx.advection(tall(z), tall(u), tall(v), xm_t, ym_t, 1.0, fdefined=ALLD, out=o_t), "advection",
         [h["z"], h["u"], h["v"], xm, ym, 1.0])
-    add("jacobian", 20, 0, lambda: ctx.jacobian(tall(z), tall(u), xm_t, ym_t, fdefined=ALLD, out=o_t), "jacobian", [h["z"], h["u"], xm, ym])
+    add("jacobian (one tall field)", 20, 0, lambda: ctx.jacobian(tall(z), tall(u), xm_t, ym_t, fdefined=ALLD, out=o_t), "jacobian", [h["z"], h["u"], xm, ym])
+    add("jacobian (level batch)", 12, 2 * 4 * n, lambda: ctx.stencil_levels("jacobian", z, u, dxm, dym, fdefined=flags, out0=out), "jacobian",
+        [h["z"], h["u"], xm, ym])
     add("thermalFrontParameter", 16, 0, lambda: ctx.thermalFrontParameter(tall(t), xm_t, ym_t, fdefined=ALLD, out=o_t),
         "thermalFrontParameter", [h["t"], xm, ym])
     add("plevelqvector c=1", 24, 0, lambda: ctx.plevelqvector(tall(z), tall(t), xm_t, ym_t, fc_t, 500.0, 1, fdefined=ALLD, out=o_t),
