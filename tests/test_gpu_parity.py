@@ -626,3 +626,30 @@ def test_shared_reciprocal_division_is_the_plain_division(gpu_ctx):
     s, p = shared.cpu().numpy(), plain.cpu().numpy()
     assert cases.same_bits(s, p, nan_payload=False)
     assert np.isfinite(p).sum() > n // 4  # the sweep is not all overflow
+
+
+def test_fused_tfp_and_qvector_random_shapes(gpu_ctx, oracle):
+    """Seeded random widths (multiples of 4, so the fused kernel runs), heights around the band sizes
+    the launcher picks, and flag modes."""
+    import mi_fieldcalc_amd.synth as synth
+
+    rng = np.random.default_rng(77)
+    for k in range(48):
+        nx = 4 * int(rng.integers(1, 200)) if k % 4 else 4 * int(rng.integers(200, 1025))
+        ny = int(rng.choice([3, 4, 5, 9, 10, 11, 17, 18, 19, 26, 27, 64, 67, 131]))
+        if nx * ny > 400000:
+            ny = max(3, 400000 // nx)
+        mode = cases.MODES[k % len(cases.MODES)]
+        seed = 5000 + k
+        xm, ym, fc = synth.grid_maps(nx, ny)
+        z = synth.scalar_field(nx, ny, seed)
+        (z_,), flag = cases._apply_mode([z], mode, seed, cases._frac(nx, ny))
+        base = dict(nx=nx, ny=ny, fdefined=flag, undef=cases.UNDEF)
+        lab = "%dx%d-%s" % (nx, ny, mode)
+        _check_case(gpu_ctx, oracle, dict(base, op="thermalFrontParameter", args=[z_, xm, ym], label="tfp-" + lab), device=bool(k & 1))
+        bad = (z_ == cases.UNDEF) | np.isnan(z_)
+        with np.errstate(all="ignore"):
+            tq = np.where(bad, z_, np.float32(250.0) + np.float32(0.05) * (z_ - np.float32(5500.0))).astype(np.float32)
+        c = 1 + k % 4
+        _check_case(gpu_ctx, oracle, dict(base, op="plevelqvector", args=[z_, tq, xm, ym, fc, 850.0, c], label="qvector%d-%s" % (c, lab)),
+                    device=bool(k & 1))
