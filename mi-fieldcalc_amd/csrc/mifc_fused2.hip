@@ -28,6 +28,8 @@
 //
 // Requirements (fused2_supported): nx % 4 == 0, nx <= 4096, 16-byte aligned
 // fields, rings fit the 160 KiB of LDS.  Everything else takes the multi-pass path.
+#include <cstdlib>
+
 #include "mifc_device.h"
 #include "mifc_kernels.h"
 
@@ -357,10 +359,13 @@ hipError_t launch(const Fused2Params& p, hipStream_t stream)
     per_cu = 1;
   const long want_blocks = 256L * (long)per_cu * 4;
   int band = (int)((interior + want_blocks - 1) / want_blocks);
-  if (band < 8)
-    band = 8;
+  if (band < 4) // one 1440x720 level: 4-row bands 16 / 20 us (TFP / Q-vector), 8-row bands 23 / 30 us, multi-pass 30 / 55 us
+    band = 4;
   if (band > 64)
     band = 64;
+  if (const char* e = std::getenv("MIFC_FUSED2_BAND")) // A/B measurements
+    if (std::atoi(e) > 0)
+      band = std::atoi(e);
   const int blocks = (interior + band - 1) / band;
   if (lds > 64 * 1024) {
     const hipError_t e =
