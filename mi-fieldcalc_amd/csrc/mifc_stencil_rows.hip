@@ -356,13 +356,23 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   const int V = (nx > 256) ? 2 : 1;
   rp.nx = nx;
   rp.ny = ny;
-  rp.R = 8;
-  rp.nbands = (ny - 2 + rp.R - 1) / rp.R;
   rp.nwc = (nx + 256 * V - 1) / (256 * V);
   rp.nlev = prm.nlev;
   int wpb = 8;
   while (wpb > 1 && wpb / 2 >= prm.nlev)
     wpb /= 2;
+  // 8-row bands; a small launch (the reference's single-field call: one level) is latency-bound and
+  // gets shorter ones -- more waves on the chip, the halo re-reads stay in L2
+  rp.R = 8;
+  if (!std::getenv("MIFC_SCALAR_ROWS_R")) {
+    while (rp.R > 2 && (long)((prm.nlev + wpb - 1) / wpb) * ((ny - 2 + rp.R - 1) / rp.R) * rp.nwc < 2048)
+      rp.R /= 2;
+  } else if (std::atoi(std::getenv("MIFC_SCALAR_ROWS_R")) > 0) {
+    rp.R = std::atoi(std::getenv("MIFC_SCALAR_ROWS_R")); // A/B measurements
+    if (rp.R > 8)
+      rp.R = 8;
+  }
+  rp.nbands = (ny - 2 + rp.R - 1) / rp.R;
   rp.wpb = wpb;
   rp.uL = (prm.nlev + wpb - 1) / wpb;
   rp.uB = rp.nbands;

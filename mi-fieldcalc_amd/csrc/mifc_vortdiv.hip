@@ -824,6 +824,14 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   Tuning t = current_tuning(nx);
   while (t.WPB > 1 && t.WPB / 2 >= prm.nlev)
     t.WPB /= 2; // fewer levels than waves: do not launch waves that only stage map factors
+  if (!std::getenv("MIFC_VORTDIV_TUNE")) {
+    // A small launch (the reference's single-field call: one level) is latency-bound: shorter
+    // bands put more waves on the chip, and their halo re-reads stay in L2.
+    // One 1440x720 level: 8-row bands 270 waves, 2-row bands 1077.
+    const long rows = prm.ny_local, wcols = (nx + 256 * t.V - 1) / (256 * t.V), groups = (prm.nlev + t.WPB - 1) / t.WPB;
+    while (t.R > 2 && groups * ((rows + t.R - 1) / t.R) * wcols < 2048)
+      t.R /= 2;
+  }
   RowsParams rp;
   rp.nx = nx;
   rp.nyg = prm.ny_global - t.PADROWS;

@@ -59,6 +59,17 @@ def test_stencils_device_resident(gpu_ctx, oracle):
         _check_case(gpu_ctx, oracle, case, device=True)
 
 
+@pytest.mark.parametrize("rows", ["1", "3", "8"])
+def test_scalar_row_kernels_band_heights(gpu_ctx, oracle, rows, monkeypatch):
+    """The one-input row-walking kernels pick their band height from the launch size; every height
+    gives the reference result (the seeded cases are small, so the default runs 2-row bands)."""
+    monkeypatch.setenv("MIFC_SCALAR_ROWS_R", rows)
+    ops = ("gradient", "plevelgwind_xcomp", "plevelgwind_ycomp", "plevelgvort", "ilevelgwind")
+    for case in cases.stencil_cases(grids=[(8, 3), (64, 48), (516, 37)]):
+        if case["op"] in ops:
+            _check_case(gpu_ctx, oracle, case, device=True)
+
+
 def test_elementwise_host_pointers(gpu_ctx, oracle):
     for case in cases.ewise_cases():
         _check_case(gpu_ctx, oracle, case, device=False)
@@ -292,7 +303,7 @@ def _expect_levels(oracle, u, v, xm, ym, flags):
 
 
 @pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 9), (516, 70, 6), (260, 11, 5), (17, 9, 7), (1440, 75, 5)])
-@pytest.mark.parametrize("tune", ["", "R=7,D=0", "R=5,D=1,NT=1", "R=64,D=1,WPB=8", "K=1", "K=1,XCD=0,NT=0", "K=2", "K=2,XCD=0"])
+@pytest.mark.parametrize("tune", ["", "R=7,D=0", "R=5,D=1,NT=1", "R=64,D=1,WPB=8", "K=1", "K=1,XCD=0,NT=0", "K=2", "K=2,XCD=0", "R=1", "R=2,WPB=2", "R=8"])
 def test_vortdiv_levels_matches_per_level_reference_calls(gpu_ctx, oracle, nx, ny, nlev, tune, monkeypatch):
     import torch
 

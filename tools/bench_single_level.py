@@ -50,3 +50,27 @@ for name, env in configs:
     tfp = lambda: ctx.thermalFrontParameter(z, dxm, dym, fdefined=fc.ALL_DEFINED, out=out)
     qv = lambda: ctx.plevelqvector(z, t, dxm, dym, dfc, 500.0, 1, fdefined=fc.ALL_DEFINED, out=out)
     print("%-22s  TFP %7.1f / %6.1f   Q-vector %7.1f / %6.1f" % (name, timed(tfp), kernel_us(tfp), timed(qv), kernel_us(qv)))
+
+# ---- the other hot-path operators on one level (default settings)
+for k in ("MIFC_FUSED2", "MIFC_FUSED2_BAND"):
+    os.environ.pop(k, None)
+u_np, v_np = synth.wind(NX, NY, 11)
+u, v = torch.from_numpy(u_np).to(dev), torch.from_numpy(v_np).to(dev)
+q = torch.full_like(z, 0.004)
+tk = torch.full_like(z, 280.0) + 0.001 * (z - 5500.0)
+ps = torch.full_like(z, 1000.0)
+out2 = torch.empty_like(z)
+print("\n%-34s %10s %10s" % ("operator, one level", "call us", "kernel us"))
+for flag_name, flag in (("ALL_DEFINED", fc.ALL_DEFINED), ("SOME_DEFINED", fc.SOME_DEFINED)):
+    ops = [
+        ("relvort", lambda: ctx.relvort(u, v, dxm, dym, fdefined=flag, out=out)),
+        ("divergence", lambda: ctx.divergence(u, v, dxm, dym, fdefined=flag, out=out)),
+        ("gradient c=3", lambda: ctx.gradient(z, dxm, dym, 3, fdefined=flag, out=out)),
+        ("plevelgvort", lambda: ctx.plevelgvort(z, dxm, dym, dfc, fdefined=flag, out=out)),
+        ("vectorabs", lambda: ctx.vectorabs(u, v, fdefined=flag, out=out)),
+        ("pleveltemp c=3", lambda: ctx.pleveltemp(tk, 850.0, "kelvin", 3, fdefined=flag, out=out)),
+        ("hlevelhum c=1", lambda: ctx.hlevelhum(tk, q, ps, 12.5, 0.73, "kelvin", 1, fdefined=flag, out=out)),
+        ("jacobian", lambda: ctx.jacobian(z, u, dxm, dym, fdefined=flag, out=out)),
+    ]
+    for name, fn in ops:
+        print("%-34s %10.1f %10.1f" % (name + " (" + flag_name + ")", timed(fn), kernel_us(fn)))
