@@ -128,9 +128,17 @@ int run_ensemble(mifc_ctx* c, mifc::EnsembleParams P, int nx, int ny, const floa
   bool ok = true;
   P.out = stage_out(c, 9, out, n, memkind, &ok, may_keep);
   const size_t table_bytes = ((size_t)nfields * sizeof(float*) + 15) & ~size_t(15);
-  if (!ok || !ensure_levels(c, 1) || !ensure_slot(c, 8, table_bytes + (size_t)nfields + 16))
+  const bool inline_table = nfields <= 64; // pointers and flags ride in the kernel arguments
+  if (!ok || !ensure_levels(c, 1) || (!inline_table && !ensure_slot(c, 8, table_bytes + (size_t)nfields + 16)))
     return 0;
-  if (nfields > 0) {
+  P.n_inline = inline_table ? 1 : 0;
+  P.has_member_flags = member_flags ? 1 : 0;
+  if (inline_table) {
+    for (int j = 0; j < nfields; ++j) {
+      P.fields_inline[j] = table[(size_t)j];
+      P.flags_inline[j] = member_flags ? (unsigned char)member_flags[j] : 0;
+    }
+  } else if (nfields > 0) {
     MIFC_HIP(c, hipMemcpyAsync(c->slot[8], table.data(), (size_t)nfields * sizeof(float*), hipMemcpyHostToDevice, c->stream));
     if (member_flags) {
       for (int j = 0; j < nfields; ++j)
@@ -141,8 +149,8 @@ int run_ensemble(mifc_ctx* c, mifc::EnsembleParams P, int nx, int ny, const floa
   P.n = (int)n;
   P.first = 0;
   P.nfields = nfields;
-  P.fields = static_cast<const float* const*>(c->slot[8]);
-  P.member_flags = member_flags ? reinterpret_cast<const unsigned char*>(static_cast<char*>(c->slot[8]) + table_bytes) : nullptr;
+  P.fields = inline_table ? nullptr : static_cast<const float* const*>(c->slot[8]);
+  P.member_flags = (member_flags && !inline_table) ? reinterpret_cast<const unsigned char*>(static_cast<char*>(c->slot[8]) + table_bytes) : nullptr;
   P.vector_ok = (reinterpret_cast<size_t>(P.out) & 15u) == 0;
   for (int j = 0; j < nfields; ++j)
     P.vector_ok = P.vector_ok && (reinterpret_cast<size_t>(table[(size_t)j]) & 15u) == 0;

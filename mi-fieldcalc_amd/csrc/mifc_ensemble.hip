@@ -119,6 +119,18 @@ __device__ __forceinline__ bool ens_finish(const EnsembleParams& P, Acc& a, floa
   return false;
 }
 
+// member j's field and ValuesDefined flag: from the kernel arguments (small ensembles) or the device table
+__device__ __forceinline__ const float* ens_field(const EnsembleParams& P, int j)
+{
+  return P.n_inline ? P.fields_inline[j] : P.fields[j];
+}
+__device__ __forceinline__ unsigned char ens_flag(const EnsembleParams& P, int j)
+{
+  if (P.n_inline)
+    return P.has_member_flags ? P.flags_inline[j] : (unsigned char)(P.all_defined ? 0 : 2);
+  return P.member_flags ? P.member_flags[j] : (unsigned char)(P.all_defined ? 0 : 2);
+}
+
 template <int OP, bool VEC4>
 __global__ __launch_bounds__(256) void ensemble_kernel(const EnsembleParams P)
 {
@@ -142,12 +154,12 @@ __global__ __launch_bounds__(256) void ensemble_kernel(const EnsembleParams P)
 #pragma unroll
         for (int k = 0; k < MB; ++k)
           if (j0 + k < P.nfields)
-            v[k] = reinterpret_cast<const float4*>(P.fields[j0 + k])[q];
+            v[k] = reinterpret_cast<const float4*>(ens_field(P, j0 + k))[q];
 #pragma unroll
         for (int k = 0; k < MB; ++k) {
           if (j0 + k < P.nfields) {
             const int j = j0 + k;
-            const unsigned char fl = P.member_flags ? P.member_flags[j] : (unsigned char)(P.all_defined ? 0 : 2);
+            const unsigned char fl = ens_flag(P, j);
             const bool m_all = fl == 0, m_none = fl == 1;
             const float f[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
 #pragma unroll
@@ -177,8 +189,8 @@ __global__ __launch_bounds__(256) void ensemble_kernel(const EnsembleParams P)
       ens_init<OP>(P, a);
       bool live = true;
       for (int j = 0; j < P.nfields && live; ++j) {
-        const unsigned char fl = P.member_flags ? P.member_flags[j] : (unsigned char)(P.all_defined ? 0 : 2);
-        live = ens_member<OP>(P, a, j, P.fields[j][i], fl == 0, fl == 1);
+        const unsigned char fl = ens_flag(P, j);
+        live = ens_member<OP>(P, a, j, ens_field(P, j)[i], fl == 0, fl == 1);
       }
       if (keep_all)
         continue;

@@ -161,6 +161,11 @@ struct EnsembleParams
   const float* const* fields; // device table of nfields device pointers
   float* out;
   u64* n_undefined;
+  // up to 64 members (an ensemble: 51) travel in the kernel arguments: no table upload before the launch
+  int n_inline;         // != 0: use the arrays below instead of `fields` / `member_flags`
+  int has_member_flags; // with n_inline: flags_inline is meaningful
+  const float* fields_inline[64];
+  unsigned char flags_inline[64];
 };
 hipError_t launch_ensemble(const EnsembleParams& prm, hipStream_t stream);
 

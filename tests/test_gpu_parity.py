@@ -217,6 +217,34 @@ def test_ensemble_51_members_full_field(gpu_ctx, oracle):
         assert ok and flag == flag_e and cases.same_bits(out.cpu().numpy(), expect, nan_payload=False), op
 
 
+@pytest.mark.parametrize("device", [False, True])
+def test_ensemble_more_members_than_ride_in_the_kernel_arguments(gpu_ctx, oracle, device):
+    """Up to 64 member pointers travel in the kernel arguments; a larger ensemble uses the device table."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nmem = 68, 21, 70
+    members = [synth.uniform((ny, nx), 9000 + k, -5.0, 30.0).astype(np.float32) for k in range(nmem)]
+    members[66] = synth.sprinkle_undef(members[66], 3, 0.05)
+    members[2] = np.full_like(members[2], cases.UNDEF)
+    flags = [ALL] * nmem
+    flags[66] = SOME
+    flags[2] = NONE
+    m = [torch.from_numpy(x).cuda() for x in members] if device else members
+    for op, args_cpu, call in (
+        ("meanValue", [members, flags], lambda: gpu_ctx.meanValue(m, flags)),
+        ("stddevValue", [members, flags], lambda: gpu_ctx.stddevValue(m, flags)),
+        ("probability", [4, members, flags, [20.0]], lambda: gpu_ctx.probability(4, m, flags, [20.0])),
+        ("extremeValue", [4, members], lambda: gpu_ctx.extremeValue(4, m, fdefined=SOME)),
+        ("sumFields", [members], lambda: gpu_ctx.sumFields(m, fdefined=SOME)),
+    ):
+        ok, expect, flag_e = oracle.call(op, nx, ny, *args_cpu, fdefined=SOME)
+        out, flag = call()
+        out = out.cpu().numpy() if device else out
+        assert ok and flag == flag_e and cases.same_bits(out, expect, nan_payload=False), op
+
+
 def test_against_golden_vectors(gpu_ctx):
     g, cs = golden_util.ensemble_golden_cases()
     for case in cs:
