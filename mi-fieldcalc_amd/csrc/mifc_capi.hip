@@ -300,11 +300,12 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
   P.n_undefined = c->d_counts;
   if (!pinned_acquire(c))
     return 0;
-  bool every_all = true;
+  bool every_all = true, any_all = false;
   for (int l = 0; l < sc.nlev; ++l) {
     const bool a = (fdefined[l] == MIFC_ALL_DEFINED);
     pinned_flags(c)[l] = a ? 1 : 0;
     every_all = every_all && a;
+    any_all = any_all || a;
   }
   // the second pass of thermalFrontParameter rejects cells (|grad T| == 0) even
   // when its input flag is ALL_DEFINED: it always runs the counting variant
@@ -312,9 +313,12 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
   if (sc.op == mifc::ST_TFP || sc.op == mifc::ST_QVEC_X || sc.op == mifc::ST_QVEC_Y)
     every_all = false;
   P.every_level_all_defined = every_all ? 1 : 0;
-  P.all_defined = c->d_flags;
+  // the kernels read a null flag array as "no level is ALL_DEFINED": the usual single-field call with
+  // undefined values in it needs no flag upload
+  P.all_defined = any_all ? c->d_flags : nullptr;
   if (!every_all) {
-    MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)sc.nlev, hipMemcpyHostToDevice, c->stream));
+    if (any_all)
+      MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)sc.nlev, hipMemcpyHostToDevice, c->stream));
     MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64) * (size_t)sc.nlev, c->stream));
   }
   if (piped) {
@@ -331,7 +335,7 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
       q.f1 = base.f1 ? d_in[1] : nullptr;
       q.out0 = d_out[0];
       q.out1 = d_out[1];
-      q.all_defined = base.all_defined + l0;
+      q.all_defined = base.all_defined ? base.all_defined + l0 : nullptr;
       q.n_undefined = base.n_undefined + l0;
       return mifc::launch_stencil(q, stream);
     };
