@@ -396,12 +396,26 @@ hipError_t launch_division_check(const float* a, const float* b, const float* g,
   return hipGetLastError();
 }
 
+// mifc_fused2_tile.hip: the same operators with one wave per workgroup and column tiles
+bool fused2_tile_supported(const Fused2Params& p);
+hipError_t launch_fused2_tile(const Fused2Params& p, hipStream_t stream);
+
+static bool tiles_enabled()
+{
+  const char* e = std::getenv("MIFC_FUSED2_TILE"); // "0": the row-wide kernel of this file (A/B measurements, tests)
+  return !(e && e[0] == '0');
+}
+
 bool fused2_supported(const Fused2Params& p)
 {
-  if (p.nx < 4 || (p.nx & 3) || p.nx > 4096 || p.ny < 3)
+  if (p.nx < 4 || (p.nx & 3) || p.ny < 3)
     return false;
-  if (lds_bytes(p) > LDS_PER_CU)
+  if (tiles_enabled()) {
+    if (!fused2_tile_supported(p))
+      return false;
+  } else if (p.nx > 4096 || lds_bytes(p) > LDS_PER_CU) {
     return false;
+  }
   if (!p.a || !p.xmapr || !p.ymapr || !p.out || !p.counts)
     return false;
   if (!aligned16(p.a) || !aligned16(p.xmapr) || !aligned16(p.ymapr) || !aligned16(p.out))
@@ -415,6 +429,8 @@ hipError_t launch_fused2(const Fused2Params& p, hipStream_t stream)
 {
   if (!fused2_supported(p))
     return hipErrorInvalidValue;
+  if (tiles_enabled())
+    return launch_fused2_tile(p, stream);
   switch (p.op) {
   case F2_TFP:
     return launch_op<F2_TFP>(p, stream);

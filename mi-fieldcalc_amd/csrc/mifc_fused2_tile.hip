@@ -1,0 +1,436 @@
+// mifc_fused2_tile.hip -- thermalFrontParameter and plevelqvector in one launch,
+// one WAVE per workgroup.
+//
+// Same pipeline as mifc_fused2.hip (source rows and the edge-filled intermediate
+// rows in LDS row rings, a band of rows walked top to bottom, loads landing in
+// LDS at the end of the iteration that issued them), but the field is also cut
+// into column tiles of 240 cells: a wave owns 60 float4 column groups and loads
+// one more on either side, so the x-neighbours of its intermediate rows are its
+// own.  A ring row is 1 KiB, the rings of a wave 8 KiB (TFP) / 13 KiB (Q-vector),
+// and since nothing is shared between waves there is no barrier at all -- the
+// LDS queue of a wave is in order.  The row-wide kernel spent half its time or
+// more waiting at its two barriers per row (profiles/r01/valu_by_kernel.txt).
+//
+// What a tile cannot see is the far edge of the field: the reference's flat loops
+// evaluate the cells of columns 0 and nx-1 with neighbours wrapped into the
+// adjacent row (mifc_stencil.hip header).  Their VALUES are overwritten by
+// fillEdges from columns 1 / nx-2, which the edge tiles own; their share of the
+// undefined COUNT is taken by fused2_edge_count_kernel below, two cells per row
+// straight from global memory.  (TFP with an ALL_DEFINED input needs no wrapped
+// neighbour for the count -- only |grad| != 0 -- and skips that launch.)
+#include <cstdlib>
+
+#include "mifc_device.h"
+#include "mifc_kernels.h"
+
+namespace mifc {
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int TW = 240;       // cells a tile owns per row
+constexpr int TS = TW + 16;   // floats per LDS row: 4 pad | halo quad | 60 owned quads | halo quad | 4 pad
+constexpr int TQ = TW / 4 + 2; // column groups a wave holds (62 of its 64 lanes)
+
+__device__ __forceinline__ float4 ld4(const float* p)
+{
+  return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void st4(float* p, const float (&v)[4])
+{
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void unpack(const float4 q, float (&v)[4])
+{
+  v[0] = q.x;
+  v[1] = q.y;
+  v[2] = q.z;
+  v[3] = q.w;
+}
+// {west, own four, east} of a ring row
+__device__ __forceinline__ void row6(const float* row, int p, float (&v)[6])
+{
+  const float4 q = ld4(row + p);
+  v[0] = row[p - 1];
+  v[1] = q.x;
+  v[2] = q.y;
+  v[3] = q.z;
+  v[4] = q.w;
+  v[5] = row[p + 4];
+}
+
+// ---- the point formulas, shared with the edge-count kernel
+// gradient compute 3, FieldCalculations.cc:2037-2046
+template <bool CHECK>
+__device__ __forceinline__ float tfp_absdelt(float s, float w, float e, float n, float xm, float ym, float undef, bool& ok)
+{
+  ok = !CHECK || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef));
+  const float dfdx = (float)(0.5 * (double)xm * (double)(e - w));
+  const float dfdy = (float)(0.5 * (double)ym * (double)(n - s));
+  return ok ? absval(dfdx, dfdy) : undef;
+}
+// plevelgwind_xcomp :660-663 (tests only if the caller's flag is not ALL_DEFINED),
+// plevelgwind_ycomp :693-698 (always tests: the x pass hands it NONE_DEFINED, :664)
+template <bool CHECK>
+__device__ __forceinline__ void qvec_gwind(float s, float w, float e, float n, float xm, float ym, float fc, float undef, float& ug, float& vg)
+{
+  const bool ok = is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef);
+  const double fd = (double)fc, finv = shared_reciprocal(fd);
+  const float u = (float)quotient(-0.5 * (double)ym * (double)(n - s) * (double)MIFC_K_G, fd, finv);
+  const float v = (float)quotient(0.5 * (double)xm * (double)(e - w) * (double)MIFC_K_G, fd, finv);
+  ug = (!CHECK || ok) ? u : undef;
+  vg = ok ? v : undef;
+}
+// thermalFrontParameter :2290-2298
+template <bool CHECK>
+__device__ __forceinline__ float tfp_point(float ts, float tw, float te, float tn, float gs, float gw, float g, float ge, float gn, float xm, float ym,
+                                           float undef, bool& ok, bool& rejected_by_test_only)
+{
+  const bool def = !CHECK || (is_def(ts, undef) && is_def(tw, undef) && is_def(te, undef) && is_def(tn, undef) && is_def(gs, undef) &&
+                              is_def(gw, undef) && is_def(g, undef) && is_def(ge, undef) && is_def(gn, undef));
+  ok = def && g != 0;
+  rejected_by_test_only = CHECK && !def && g != 0;
+  const double hx = 0.5 * (double)xm, hy = 0.5 * (double)ym;
+  const float dabsdeltdx = (float)(hx * (double)(ge - gw));
+  const float dabsdeltdy = (float)(hy * (double)(gn - gs));
+  const double gd = (double)g, ginv = shared_reciprocal(gd);
+  const float dtdxa = (float)quotient(hx * (double)(te - tw), gd, ginv);
+  const float dtdya = (float)quotient(hy * (double)(tn - ts), gd, ginv);
+  return ok ? -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya) : undef;
+}
+// plevelqvector :570-584, "!= undef" only
+template <int OP>
+__device__ __forceinline__ float qvec_point(float us, float uw, float ue, float un, float vs, float vw, float ve, float vn, float ts, float tw, float te,
+                                            float tn, float xm, float ym, float scale, float scale2, float undef, bool& ok)
+{
+  ok = us != undef && uw != undef && ue != undef && un != undef && vs != undef && vw != undef && ve != undef && vn != undef && ts != undef &&
+       tw != undef && te != undef && tn != undef;
+  const double hx = 0.5 * (double)xm, hy = 0.5 * (double)ym;
+  const float dtdx = (float)(hx * (double)scale * (double)(te - tw));
+  const float dtdy = (float)(hy * (double)scale * (double)(tn - ts));
+  float q;
+  if (OP == F2_QVEC_X) {
+    const float dugdx = (float)(hx * (double)(ue - uw));
+    const float dvgdx = (float)(hx * (double)(ve - vw));
+    q = scale2 * (dugdx * dtdx + dvgdx * dtdy);
+  } else {
+    const float dugdy = (float)(hy * (double)(un - us));
+    const float dvgdy = (float)(hy * (double)(vn - vs));
+    q = scale2 * (dugdy * dtdx + dvgdy * dtdy);
+  }
+  return ok ? q : undef;
+}
+
+template <int OP, bool CHECK>
+__global__ __launch_bounds__(64) void fused2_tile_kernel(const Fused2Params P, const int band, const int ntiles)
+{
+  constexpr bool TFP = OP == F2_TFP;
+  constexpr int RA = TFP ? 5 : 3; // TFP reads its source rows in the last stage too
+  constexpr int ROWS = TFP ? RA + 3 : RA + 4 + 3 + 3;
+  __shared__ float4 lds4[ROWS * TS / 4];
+  float* ringA = reinterpret_cast<float*>(lds4); // source rows: tx | z
+  float* ringT = ringA + RA * TS;                // Q-vector: temperature rows (4)
+  float* mid0 = ringT + (TFP ? 0 : 4 * TS);      // |grad tx| | ug, edge-filled (3)
+  float* mid1 = mid0 + 3 * TS;                   // Q-vector: vg, edge-filled (3)
+
+  const int nx = P.nx, ny = P.ny;
+  const int lane = threadIdx.x;
+  const int tile = (int)blockIdx.x % ntiles;
+  const int bidx = (int)blockIdx.x / ntiles;
+  const int xq = tile * TW - 4 + 4 * lane; // first column of this lane's group; lanes 0 and 61 hold the halo groups
+  const bool loadable = lane < TQ && xq >= 0 && xq < nx;
+  const bool owned = loadable && lane >= 1 && lane <= TW / 4;
+  const int p = 4 + 4 * lane;                 // position of the group in a ring row
+  const bool fill_w = xq == 0, fill_e = xq + 4 == nx; // the group holds column 0 / column nx-1 of the field
+  const float undef = P.undef;
+
+  const int jb0 = 1 + bidx * band;
+  const int jb1 = (jb0 + band < ny - 1) ? jb0 + band : ny - 1;
+  const int rs = jb0 - 2, re = jb1 + 1;
+
+  const size_t ccol = (size_t)(loadable ? xq : tile * TW); // other lanes load a valid address and use nothing
+  if (loadable && rs >= 0)
+    *reinterpret_cast<float4*>(ringA + (rs % RA) * TS + p) = ld4(P.a + (size_t)rs * nx + ccol);
+  unsigned int n1 = 0, n2 = 0, n2c = 0;
+
+  struct RowMaps
+  {
+    float4 xm, ym, fc;
+  };
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  RowMaps m0 = {zero4, zero4, zero4}, m1 = m0, m2 = m0;
+
+  // One iteration (see mifc_fused2.hip for the pipeline and the ring depths; with one wave per
+  // workgroup the rings have a single reader/writer and the LDS queue keeps them in order).
+  auto iteration = [&](const int r, RowMaps& m_new /* row r */, const RowMaps& m_a /* row r-1 */, const RowMaps& m_b /* row r-2 */)
+                       __attribute__((always_inline)) {
+    const bool load_a = r < re && r + 1 >= 0 && r + 1 < ny;
+    const bool load_row = r < re && r >= 0 && r < ny;
+    const size_t row_a = (size_t)(r + 1 < 0 ? 0 : (r + 1 > ny - 1 ? ny - 1 : r + 1)) * nx + ccol;
+    const size_t row_m = (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + ccol;
+    const float4 pa = ld4(P.a + row_a); // in flight until the end of the iteration: A(r+1), t(r), maps(r)
+    float4 pt = zero4;
+    m_new.xm = ld4(P.xmapr + row_m);
+    m_new.ym = ld4(P.ymapr + row_m);
+    if (!TFP) {
+      m_new.fc = ld4(P.fcoriolis + row_m);
+      pt = ld4(P.t + row_m);
+    }
+
+    // ---- stage A: intermediate row y = r-1, for every group the wave holds (halo groups included)
+    const int y = r - 1;
+    if (loadable && y >= 1 && y <= ny - 2 && y >= jb0 - 1 && y <= jb1) {
+      const float* Sr = ringA + ((y - 1) % RA) * TS;
+      const float* Cr = ringA + (y % RA) * TS;
+      const float* Nr = ringA + ((y + 1) % RA) * TS;
+      float sv[4], nv[4], cv[6], xm[4], ym[4];
+      unpack(ld4(Sr + p), sv);
+      unpack(ld4(Nr + p), nv);
+      row6(Cr, p, cv);
+      unpack(m_a.xm, xm);
+      unpack(m_a.ym, ym);
+      if (TFP) {
+        const bool counted = CHECK && owned && y >= jb0 && y < jb1; // every cell is counted by the wave that owns it
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bool ok;
+          g[k] = tfp_absdelt<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], undef, ok);
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3); // counted by fused2_edge_count_kernel
+          if (counted && !edge_cell && !ok)
+            ++n1;
+        }
+        if (fill_w)
+          g[0] = g[1];
+        if (fill_e)
+          g[3] = g[2];
+        st4(mid0 + (y % 3) * TS + p, g);
+      } else {
+        float fc[4], ug[4], vg[4];
+        unpack(m_a.fc, fc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          qvec_gwind<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], fc[k], undef, ug[k], vg[k]);
+        if (fill_w) {
+          ug[0] = ug[1];
+          vg[0] = vg[1];
+        }
+        if (fill_e) {
+          ug[3] = ug[2];
+          vg[3] = vg[2];
+        }
+        st4(mid0 + (y % 3) * TS + p, ug);
+        st4(mid1 + (y % 3) * TS + p, vg);
+      }
+    }
+
+    // ---- stage B: result row j = r-2, owned groups
+    const int j = r - 2;
+    const bool have_row = owned && j >= jb0 && j < jb1;
+    float o[4] = {undef, undef, undef, undef};
+    if (have_row) {
+      const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > ny - 2) ? ny - 2 : j + 1; // filled intermediate rows 0 / ny-1 are rows 1 / ny-2
+      float xm[4], ym[4];
+      unpack(m_b.xm, xm);
+      unpack(m_b.ym, ym);
+      if (TFP) {
+        float gs[4], gn[4], gc[6], ts[4], tn[4], tc[6];
+        unpack(ld4(mid0 + (js % 3) * TS + p), gs);
+        unpack(ld4(mid0 + (jn % 3) * TS + p), gn);
+        row6(mid0 + (j % 3) * TS, p, gc);
+        unpack(ld4(ringA + ((j - 1) % RA) * TS + p), ts);
+        unpack(ld4(ringA + ((j + 1) % RA) * TS + p), tn);
+        row6(ringA + (j % RA) * TS, p, tc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bool ok, by_test;
+          o[k] = tfp_point<CHECK>(ts[k], tc[k], tc[k + 2], tn[k], gs[k], gc[k], gc[k + 1], gc[k + 2], gn[k], xm[k], ym[k], undef, ok, by_test);
+          // the cells of columns 0 / nx-1 need wrapped neighbours for their tests: the edge kernel counts
+          // them -- unless nothing is tested, then |grad| != 0 of the filled value is all there is
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
+          if (!(CHECK && edge_cell)) {
+            n2 += ok ? 0u : 1u;
+            if (by_test)
+              ++n2c;
+          }
+        }
+      } else {
+        float us[4], un[4], uc[6], vs[4], vn[4], vc[6], ts[4], tn[4], tc[6];
+        unpack(ld4(mid0 + (js % 3) * TS + p), us);
+        unpack(ld4(mid0 + (jn % 3) * TS + p), un);
+        row6(mid0 + (j % 3) * TS, p, uc);
+        unpack(ld4(mid1 + (js % 3) * TS + p), vs);
+        unpack(ld4(mid1 + (jn % 3) * TS + p), vn);
+        row6(mid1 + (j % 3) * TS, p, vc);
+        unpack(ld4(ringT + ((j - 1) % 4) * TS + p), ts);
+        unpack(ld4(ringT + ((j + 1) % 4) * TS + p), tn);
+        row6(ringT + (j % 4) * TS, p, tc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bool ok;
+          o[k] = qvec_point<OP>(us[k], uc[k], uc[k + 2], un[k], vs[k], vc[k], vc[k + 2], vn[k], ts[k], tc[k], tc[k + 2], tn[k], xm[k], ym[k], P.scale,
+                                P.scale2, undef, ok);
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
+          if (!edge_cell)
+            n2 += ok ? 0u : 1u;
+        }
+      }
+      // fillEdges on the result: columns, then rows 0 / ny-1
+      if (fill_w)
+        o[0] = o[1];
+      if (fill_e)
+        o[3] = o[2];
+    }
+    // rows that were in flight since the top of the iteration; the explicit vmcnt(0) (all paths,
+    // loads only by now) keeps the compiler from waiting again -- behind the store -- at the loop edge
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (loadable) {
+      if (load_a)
+        *reinterpret_cast<float4*>(ringA + ((r + 1) % RA) * TS + p) = pa;
+      if (!TFP && load_row)
+        *reinterpret_cast<float4*>(ringT + (r % 4) * TS + p) = pt;
+    }
+    if (have_row) {
+      const v4f q = {o[0], o[1], o[2], o[3]};
+      __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)j * nx + xq));
+      if (j == 1)
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + xq));
+      if (j == ny - 2)
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)(ny - 1) * nx + xq));
+    }
+  };
+  for (int r = rs; r <= re; r += 3) {
+    iteration(r, m0, m2, m1);
+    if (r + 1 > re)
+      break;
+    iteration(r + 1, m1, m0, m2);
+    if (r + 2 > re)
+      break;
+    iteration(r + 2, m2, m1, m0);
+  }
+  if (TFP && CHECK) {
+    wave_count_add(P.counts + 0, n1);
+    wave_count_add(P.counts + 2, n2c);
+  }
+  wave_count_add(P.counts + 1, n2);
+}
+
+// The cells of columns 0 and nx-1, rows 1..ny-2: only their contribution to the counts (their values
+// are fill copies).  Lane = (row, side); everything comes from global memory, with the neighbours the
+// flat loop of the reference sees: west of column 0 is (nx-1, j-1), east of column nx-1 is (0, j+1).
+template <int OP, bool CHECK>
+__global__ __launch_bounds__(256) void fused2_edge_count_kernel(const Fused2Params P)
+{
+  constexpr bool TFP = OP == F2_TFP;
+  const int nx = P.nx, ny = P.ny;
+  const float undef = P.undef;
+  auto at = [&](const float* f, int x, int y) { return f[(size_t)y * nx + x]; };
+  auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+  // intermediate fields after their fillEdges: the raw value at the clamped position (always an interior cell)
+  auto absdelt_filled = [&](int x, int y) {
+    x = clampi(x, 1, nx - 2);
+    y = clampi(y, 1, ny - 2);
+    bool ok;
+    return tfp_absdelt<CHECK>(at(P.a, x, y - 1), at(P.a, x - 1, y), at(P.a, x + 1, y), at(P.a, x, y + 1), at(P.xmapr, x, y), at(P.ymapr, x, y), undef, ok);
+  };
+  auto gwind_filled = [&](int x, int y, float& ug, float& vg) {
+    x = clampi(x, 1, nx - 2);
+    y = clampi(y, 1, ny - 2);
+    qvec_gwind<CHECK>(at(P.a, x, y - 1), at(P.a, x - 1, y), at(P.a, x + 1, y), at(P.a, x, y + 1), at(P.xmapr, x, y), at(P.ymapr, x, y),
+                      at(P.fcoriolis, x, y), undef, ug, vg);
+  };
+  unsigned int n1 = 0, n2 = 0, n2c = 0;
+  const int cells = 2 * (ny - 2);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += gridDim.x * blockDim.x) {
+    const int j = 1 + (i >> 1);
+    const bool left = (i & 1) == 0;
+    const int x = left ? 0 : nx - 1;
+    // flat-index neighbours
+    const int wx = left ? nx - 1 : nx - 2, wy = left ? j - 1 : j;
+    const int ex = left ? 1 : 0, ey = left ? j : j + 1;
+    if (TFP) {
+      const float ts = at(P.a, x, j - 1), tw = at(P.a, wx, wy), te = at(P.a, ex, ey), tn = at(P.a, x, j + 1);
+      if (CHECK && !(is_def(ts, undef) && is_def(tw, undef) && is_def(te, undef) && is_def(tn, undef)))
+        ++n1; // gradient compute 3 :2039
+      bool ok, by_test;
+      (void)tfp_point<CHECK>(ts, tw, te, tn, absdelt_filled(x, j - 1), absdelt_filled(wx, wy), absdelt_filled(x, j), absdelt_filled(ex, ey),
+                             absdelt_filled(x, j + 1), at(P.xmapr, x, j), at(P.ymapr, x, j), undef, ok, by_test);
+      n2 += ok ? 0u : 1u;
+      if (by_test)
+        ++n2c;
+    } else {
+      float us, uw, ue, un, vs, vw, ve, vn;
+      gwind_filled(x, j - 1, us, vs);
+      gwind_filled(wx, wy, uw, vw);
+      gwind_filled(ex, ey, ue, ve);
+      gwind_filled(x, j + 1, un, vn);
+      bool ok;
+      (void)qvec_point<OP>(us, uw, ue, un, vs, vw, ve, vn, at(P.t, x, j - 1), at(P.t, wx, wy), at(P.t, ex, ey), at(P.t, x, j + 1), at(P.xmapr, x, j),
+                           at(P.ymapr, x, j), P.scale, P.scale2, undef, ok);
+      n2 += ok ? 0u : 1u;
+    }
+  }
+  if (TFP && CHECK) {
+    wave_count_add(P.counts + 0, n1);
+    wave_count_add(P.counts + 2, n2c);
+  }
+  wave_count_add(P.counts + 1, n2);
+}
+
+template <int OP, bool CHECK>
+hipError_t launch(const Fused2Params& p, hipStream_t stream)
+{
+  const int interior = p.ny - 2;
+  const int ntiles = (p.nx + TW - 1) / TW;
+  // enough workgroups to fill the chip several times over (16-20 single-wave workgroups fit a CU),
+  // bands tall enough that the 4 (source) + 2 (maps) halo rows a band re-reads stay a small fraction
+  const long want_bands = (256L * 16 * 4 + ntiles - 1) / ntiles;
+  int band = (int)((interior + want_bands - 1) / want_bands);
+  if (band < 4)
+    band = 4;
+  if (band > 64)
+    band = 64;
+  if (const char* e = std::getenv("MIFC_FUSED2_BAND")) // A/B measurements
+    if (std::atoi(e) > 0)
+      band = std::atoi(e);
+  const int nbands = (interior + band - 1) / band;
+  hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(nbands * ntiles)), dim3(64), 0, stream, p, band, ntiles);
+  if (OP != F2_TFP || CHECK) {
+    int g = (2 * interior + 255) / 256;
+    if (g > 1024)
+      g = 1024;
+    hipLaunchKernelGGL((fused2_edge_count_kernel<OP, CHECK>), dim3((unsigned)g), dim3(256), 0, stream, p);
+  }
+  return hipGetLastError();
+}
+
+template <int OP>
+hipError_t launch_op(const Fused2Params& p, hipStream_t stream)
+{
+  return p.check ? launch<OP, true>(p, stream) : launch<OP, false>(p, stream);
+}
+
+} // namespace
+
+bool fused2_tile_supported(const Fused2Params& p)
+{
+  // alignment and pointers are checked by fused2_supported(); the tiles have no width limit
+  return p.nx >= 4 && (p.nx & 3) == 0 && p.ny >= 3 && (long)((p.nx + TW - 1) / TW) * ((p.ny - 2 + 3) / 4) < 0x7fffffffL;
+}
+
+hipError_t launch_fused2_tile(const Fused2Params& p, hipStream_t stream)
+{
+  switch (p.op) {
+  case F2_TFP:
+    return launch_op<F2_TFP>(p, stream);
+  case F2_QVEC_X:
+    return launch_op<F2_QVEC_X>(p, stream);
+  case F2_QVEC_Y:
+    return launch_op<F2_QVEC_Y>(p, stream);
+  default:
+    return hipErrorInvalidValue;
+  }
+}
+
+} // namespace mifc
