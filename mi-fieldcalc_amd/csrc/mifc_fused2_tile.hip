@@ -15,9 +15,9 @@
 // evaluate the cells of columns 0 and nx-1 with neighbours wrapped into the
 // adjacent row (mifc_stencil.hip header).  Their VALUES are overwritten by
 // fillEdges from columns 1 / nx-2, which the edge tiles own; their share of the
-// undefined COUNT is taken by fused2_edge_count_kernel below, two cells per row
-// straight from global memory.  (TFP with an ALL_DEFINED input needs no wrapped
-// neighbour for the count -- only |grad| != 0 -- and skips that launch.)
+// undefined COUNT is taken by a few extra workgroups of the same launch
+// (edge_count_cells below), two cells per row straight from global memory.  (TFP with an ALL_DEFINED input needs no wrapped
+// neighbour for the count -- only |grad| != 0 -- and has no such workgroups.)
 #include <cstdlib>
 
 #include "mifc_device.h"
@@ -47,6 +47,18 @@ __device__ __forceinline__ void unpack(const float4 q, float (&v)[4])
   v[1] = q.y;
   v[2] = q.z;
   v[3] = q.w;
+}
+// lane i <- lane i-1 / lane i+1 (wave shifts; the edge lane keeps `keep_if_none`).  Every lane of the
+// wave must be active where these are called: a disabled source lane leaves the destination unchanged.
+__device__ __forceinline__ float from_lower_lane(float keep_if_none, float x)
+{
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_upper_lane(float keep_if_none, float x)
+{
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
 }
 // {west, own four, east} of a ring row
 __device__ __forceinline__ void row6(const float* row, int p, float (&v)[6])
@@ -122,205 +134,26 @@ __device__ __forceinline__ float qvec_point(float us, float uw, float ue, float 
   return ok ? q : undef;
 }
 
-template <int OP, bool CHECK>
-__global__ __launch_bounds__(64) void fused2_tile_kernel(const Fused2Params P, const int band, const int ntiles)
+// |grad tx| after its fillEdges: the raw value at the clamped position (always an interior cell), from
+// global memory.  Out of line on purpose: five of these inlined into one edge cell made the compiler
+// spill a thousand scalar registers; the edge cells are 2 per row, a call costs nothing that matters.
+template <bool CHECK>
+__device__ __attribute__((noinline)) float absdelt_filled_at(const Fused2Params& P, int x, int y)
 {
-  constexpr bool TFP = OP == F2_TFP;
-  constexpr int RA = TFP ? 5 : 3; // TFP reads its source rows in the last stage too
-  constexpr int ROWS = TFP ? RA + 3 : RA + 4 + 3 + 3;
-  __shared__ float4 lds4[ROWS * TS / 4];
-  float* ringA = reinterpret_cast<float*>(lds4); // source rows: tx | z
-  float* ringT = ringA + RA * TS;                // Q-vector: temperature rows (4)
-  float* mid0 = ringT + (TFP ? 0 : 4 * TS);      // |grad tx| | ug, edge-filled (3)
-  float* mid1 = mid0 + 3 * TS;                   // Q-vector: vg, edge-filled (3)
-
-  const int nx = P.nx, ny = P.ny;
-  const int lane = threadIdx.x;
-  const int tile = (int)blockIdx.x % ntiles;
-  const int bidx = (int)blockIdx.x / ntiles;
-  const int xq = tile * TW - 4 + 4 * lane; // first column of this lane's group; lanes 0 and 61 hold the halo groups
-  const bool loadable = lane < TQ && xq >= 0 && xq < nx;
-  const bool owned = loadable && lane >= 1 && lane <= TW / 4;
-  const int p = 4 + 4 * lane;                 // position of the group in a ring row
-  const bool fill_w = xq == 0, fill_e = xq + 4 == nx; // the group holds column 0 / column nx-1 of the field
-  const float undef = P.undef;
-
-  const int jb0 = 1 + bidx * band;
-  const int jb1 = (jb0 + band < ny - 1) ? jb0 + band : ny - 1;
-  const int rs = jb0 - 2, re = jb1 + 1;
-
-  const size_t ccol = (size_t)(loadable ? xq : tile * TW); // other lanes load a valid address and use nothing
-  if (loadable && rs >= 0)
-    *reinterpret_cast<float4*>(ringA + (rs % RA) * TS + p) = ld4(P.a + (size_t)rs * nx + ccol);
-  unsigned int n1 = 0, n2 = 0, n2c = 0;
-
-  struct RowMaps
-  {
-    float4 xm, ym, fc;
-  };
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  RowMaps m0 = {zero4, zero4, zero4}, m1 = m0, m2 = m0;
-
-  // One iteration (see mifc_fused2.hip for the pipeline and the ring depths; with one wave per
-  // workgroup the rings have a single reader/writer and the LDS queue keeps them in order).
-  auto iteration = [&](const int r, RowMaps& m_new /* row r */, const RowMaps& m_a /* row r-1 */, const RowMaps& m_b /* row r-2 */)
-                       __attribute__((always_inline)) {
-    const bool load_a = r < re && r + 1 >= 0 && r + 1 < ny;
-    const bool load_row = r < re && r >= 0 && r < ny;
-    const size_t row_a = (size_t)(r + 1 < 0 ? 0 : (r + 1 > ny - 1 ? ny - 1 : r + 1)) * nx + ccol;
-    const size_t row_m = (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + ccol;
-    const float4 pa = ld4(P.a + row_a); // in flight until the end of the iteration: A(r+1), t(r), maps(r)
-    float4 pt = zero4;
-    m_new.xm = ld4(P.xmapr + row_m);
-    m_new.ym = ld4(P.ymapr + row_m);
-    if (!TFP) {
-      m_new.fc = ld4(P.fcoriolis + row_m);
-      pt = ld4(P.t + row_m);
-    }
-
-    // ---- stage A: intermediate row y = r-1, for every group the wave holds (halo groups included)
-    const int y = r - 1;
-    if (loadable && y >= 1 && y <= ny - 2 && y >= jb0 - 1 && y <= jb1) {
-      const float* Sr = ringA + ((y - 1) % RA) * TS;
-      const float* Cr = ringA + (y % RA) * TS;
-      const float* Nr = ringA + ((y + 1) % RA) * TS;
-      float sv[4], nv[4], cv[6], xm[4], ym[4];
-      unpack(ld4(Sr + p), sv);
-      unpack(ld4(Nr + p), nv);
-      row6(Cr, p, cv);
-      unpack(m_a.xm, xm);
-      unpack(m_a.ym, ym);
-      if (TFP) {
-        const bool counted = CHECK && owned && y >= jb0 && y < jb1; // every cell is counted by the wave that owns it
-        float g[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          bool ok;
-          g[k] = tfp_absdelt<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], undef, ok);
-          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3); // counted by fused2_edge_count_kernel
-          if (counted && !edge_cell && !ok)
-            ++n1;
-        }
-        if (fill_w)
-          g[0] = g[1];
-        if (fill_e)
-          g[3] = g[2];
-        st4(mid0 + (y % 3) * TS + p, g);
-      } else {
-        float fc[4], ug[4], vg[4];
-        unpack(m_a.fc, fc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          qvec_gwind<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], fc[k], undef, ug[k], vg[k]);
-        if (fill_w) {
-          ug[0] = ug[1];
-          vg[0] = vg[1];
-        }
-        if (fill_e) {
-          ug[3] = ug[2];
-          vg[3] = vg[2];
-        }
-        st4(mid0 + (y % 3) * TS + p, ug);
-        st4(mid1 + (y % 3) * TS + p, vg);
-      }
-    }
-
-    // ---- stage B: result row j = r-2, owned groups
-    const int j = r - 2;
-    const bool have_row = owned && j >= jb0 && j < jb1;
-    float o[4] = {undef, undef, undef, undef};
-    if (have_row) {
-      const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > ny - 2) ? ny - 2 : j + 1; // filled intermediate rows 0 / ny-1 are rows 1 / ny-2
-      float xm[4], ym[4];
-      unpack(m_b.xm, xm);
-      unpack(m_b.ym, ym);
-      if (TFP) {
-        float gs[4], gn[4], gc[6], ts[4], tn[4], tc[6];
-        unpack(ld4(mid0 + (js % 3) * TS + p), gs);
-        unpack(ld4(mid0 + (jn % 3) * TS + p), gn);
-        row6(mid0 + (j % 3) * TS, p, gc);
-        unpack(ld4(ringA + ((j - 1) % RA) * TS + p), ts);
-        unpack(ld4(ringA + ((j + 1) % RA) * TS + p), tn);
-        row6(ringA + (j % RA) * TS, p, tc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          bool ok, by_test;
-          o[k] = tfp_point<CHECK>(ts[k], tc[k], tc[k + 2], tn[k], gs[k], gc[k], gc[k + 1], gc[k + 2], gn[k], xm[k], ym[k], undef, ok, by_test);
-          // the cells of columns 0 / nx-1 need wrapped neighbours for their tests: the edge kernel counts
-          // them -- unless nothing is tested, then |grad| != 0 of the filled value is all there is
-          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
-          if (!(CHECK && edge_cell)) {
-            n2 += ok ? 0u : 1u;
-            if (by_test)
-              ++n2c;
-          }
-        }
-      } else {
-        float us[4], un[4], uc[6], vs[4], vn[4], vc[6], ts[4], tn[4], tc[6];
-        unpack(ld4(mid0 + (js % 3) * TS + p), us);
-        unpack(ld4(mid0 + (jn % 3) * TS + p), un);
-        row6(mid0 + (j % 3) * TS, p, uc);
-        unpack(ld4(mid1 + (js % 3) * TS + p), vs);
-        unpack(ld4(mid1 + (jn % 3) * TS + p), vn);
-        row6(mid1 + (j % 3) * TS, p, vc);
-        unpack(ld4(ringT + ((j - 1) % 4) * TS + p), ts);
-        unpack(ld4(ringT + ((j + 1) % 4) * TS + p), tn);
-        row6(ringT + (j % 4) * TS, p, tc);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          bool ok;
-          o[k] = qvec_point<OP>(us[k], uc[k], uc[k + 2], un[k], vs[k], vc[k], vc[k + 2], vn[k], ts[k], tc[k], tc[k + 2], tn[k], xm[k], ym[k], P.scale,
-                                P.scale2, undef, ok);
-          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
-          if (!edge_cell)
-            n2 += ok ? 0u : 1u;
-        }
-      }
-      // fillEdges on the result: columns, then rows 0 / ny-1
-      if (fill_w)
-        o[0] = o[1];
-      if (fill_e)
-        o[3] = o[2];
-    }
-    // rows that were in flight since the top of the iteration; the explicit vmcnt(0) (all paths,
-    // loads only by now) keeps the compiler from waiting again -- behind the store -- at the loop edge
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (loadable) {
-      if (load_a)
-        *reinterpret_cast<float4*>(ringA + ((r + 1) % RA) * TS + p) = pa;
-      if (!TFP && load_row)
-        *reinterpret_cast<float4*>(ringT + (r % 4) * TS + p) = pt;
-    }
-    if (have_row) {
-      const v4f q = {o[0], o[1], o[2], o[3]};
-      __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)j * nx + xq));
-      if (j == 1)
-        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + xq));
-      if (j == ny - 2)
-        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)(ny - 1) * nx + xq));
-    }
-  };
-  for (int r = rs; r <= re; r += 3) {
-    iteration(r, m0, m2, m1);
-    if (r + 1 > re)
-      break;
-    iteration(r + 1, m1, m0, m2);
-    if (r + 2 > re)
-      break;
-    iteration(r + 2, m2, m1, m0);
-  }
-  if (TFP && CHECK) {
-    wave_count_add(P.counts + 0, n1);
-    wave_count_add(P.counts + 2, n2c);
-  }
-  wave_count_add(P.counts + 1, n2);
+  const int nx = P.nx;
+  x = x < 1 ? 1 : (x > nx - 2 ? nx - 2 : x);
+  y = y < 1 ? 1 : (y > P.ny - 2 ? P.ny - 2 : y);
+  const size_t c = (size_t)y * nx + x;
+  bool ok;
+  return tfp_absdelt<CHECK>(P.a[c - nx], P.a[c - 1], P.a[c + 1], P.a[c + nx], P.xmapr[c], P.ymapr[c], P.undef, ok);
 }
 
 // The cells of columns 0 and nx-1, rows 1..ny-2: only their contribution to the counts (their values
-// are fill copies).  Lane = (row, side); everything comes from global memory, with the neighbours the
+// are fill copies).  Run by a few extra workgroups at the end of the grid (Q-vector) or a small launch
+// of their own (TFP with a tested input); lane = (row, side); everything comes from global memory, with the neighbours the
 // flat loop of the reference sees: west of column 0 is (nx-1, j-1), east of column nx-1 is (0, j+1).
 template <int OP, bool CHECK>
-__global__ __launch_bounds__(256) void fused2_edge_count_kernel(const Fused2Params P)
+__device__ __forceinline__ void edge_count_cells(const Fused2Params& P, const int first, const int stride)
 {
   constexpr bool TFP = OP == F2_TFP;
   const int nx = P.nx, ny = P.ny;
@@ -328,12 +161,7 @@ __global__ __launch_bounds__(256) void fused2_edge_count_kernel(const Fused2Para
   auto at = [&](const float* f, int x, int y) { return f[(size_t)y * nx + x]; };
   auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
   // intermediate fields after their fillEdges: the raw value at the clamped position (always an interior cell)
-  auto absdelt_filled = [&](int x, int y) {
-    x = clampi(x, 1, nx - 2);
-    y = clampi(y, 1, ny - 2);
-    bool ok;
-    return tfp_absdelt<CHECK>(at(P.a, x, y - 1), at(P.a, x - 1, y), at(P.a, x + 1, y), at(P.a, x, y + 1), at(P.xmapr, x, y), at(P.ymapr, x, y), undef, ok);
-  };
+  auto absdelt_filled = [&](int x, int y) { return absdelt_filled_at<CHECK>(P, x, y); };
   auto gwind_filled = [&](int x, int y, float& ug, float& vg) {
     x = clampi(x, 1, nx - 2);
     y = clampi(y, 1, ny - 2);
@@ -342,7 +170,7 @@ __global__ __launch_bounds__(256) void fused2_edge_count_kernel(const Fused2Para
   };
   unsigned int n1 = 0, n2 = 0, n2c = 0;
   const int cells = 2 * (ny - 2);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cells; i += gridDim.x * blockDim.x) {
+  for (int i = first; i < cells; i += stride) {
     const int j = 1 + (i >> 1);
     const bool left = (i & 1) == 0;
     const int x = left ? 0 : nx - 1;
@@ -378,6 +206,228 @@ __global__ __launch_bounds__(256) void fused2_edge_count_kernel(const Fused2Para
   wave_count_add(P.counts + 1, n2);
 }
 
+// Ring depths.  One wave reads and writes its rings in program order, so a row may be replaced as soon
+// as its last read has been ISSUED: source rows r-2..r+1 are live after iteration r for TFP (its last
+// stage reads rows r-3..r-1 of the source again), r-1..r+1 for the Q-vector; intermediate rows r-3..r-1.
+template <int OP, bool CHECK>
+__global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_tile_kernel(const Fused2Params P, const int band, const int ntiles, const int n_main)
+{
+  constexpr bool TFP = OP == F2_TFP;
+  if (!TFP && (int)blockIdx.x >= n_main) { // Q-vector: the workgroups behind the tiles count the edge-column cells
+    edge_count_cells<OP, CHECK>(P, ((int)blockIdx.x - n_main) * 64 + (int)threadIdx.x, ((int)gridDim.x - n_main) * 64);
+    return;
+  }
+  constexpr int RA = TFP ? 4 : 3;
+  constexpr int ROWS = TFP ? RA + 3 : RA + 3 + 3;
+  __shared__ float4 lds4[ROWS * TS / 4];
+  float* ringA = reinterpret_cast<float*>(lds4); // source rows: tx | z
+  float* mid0 = ringA + RA * TS;                 // |grad tx| | ug, edge-filled (3)
+  float* mid1 = mid0 + 3 * TS;                   // Q-vector: vg, edge-filled (3)
+  // The Q-vector's temperature rows stay in registers (three rows of the lane's own column group; the
+  // x-neighbours of the middle one come from the adjacent lanes): 9 instead of 12 KiB of LDS per wave
+  // is the difference between 13 and 16 waves on a CU.
+
+  const int nx = P.nx, ny = P.ny;
+  const int lane = threadIdx.x;
+  const int tile = (int)blockIdx.x % ntiles;
+  const int bidx = (int)blockIdx.x / ntiles;
+  const int xq = tile * TW - 4 + 4 * lane; // first column of this lane's group; lanes 0 and 61 hold the halo groups
+  const bool loadable = lane < TQ && xq >= 0 && xq < nx;
+  const bool owned = loadable && lane >= 1 && lane <= TW / 4;
+  const int p = 4 + 4 * lane;                 // position of the group in a ring row
+  const bool fill_w = xq == 0, fill_e = xq + 4 == nx; // the group holds column 0 / column nx-1 of the field
+  const float undef = P.undef;
+
+  const int jb0 = 1 + bidx * band;
+  const int jb1 = (jb0 + band < ny - 1) ? jb0 + band : ny - 1;
+  const int rs = jb0 - 2, re = jb1 + 1;
+
+  const size_t ccol = (size_t)(loadable ? xq : tile * TW); // other lanes load a valid address and use nothing
+  if (loadable && rs >= 0)
+    *reinterpret_cast<float4*>(ringA + (rs % RA) * TS + p) = ld4(P.a + (size_t)rs * nx + ccol);
+  unsigned int n1 = 0, n2 = 0, n2c = 0;
+
+  struct RowMaps // what a lane keeps of a row beyond the iteration that loads it: map factors, and the Q-vector's temperature
+  {
+    float4 xm, ym, fc, t;
+  };
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  RowMaps m0 = {zero4, zero4, zero4, zero4}, m1 = m0, m2 = m0;
+  float4 t_south = zero4; // temperature row r-3
+
+  // One iteration (see mifc_fused2.hip for the pipeline and the ring depths; with one wave per
+  // workgroup the rings have a single reader/writer and the LDS queue keeps them in order).
+  auto iteration = [&](const int r, RowMaps& m_new /* row r */, const RowMaps& m_a /* row r-1 */, const RowMaps& m_b /* row r-2 */)
+                       __attribute__((always_inline)) {
+    const bool load_a = r < re && r + 1 >= 0 && r + 1 < ny;
+    const size_t row_a = (size_t)(r + 1 < 0 ? 0 : (r + 1 > ny - 1 ? ny - 1 : r + 1)) * nx + ccol;
+    const size_t row_m = (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + ccol;
+    const float4 pa = ld4(P.a + row_a); // in flight until the end of the iteration: A(r+1), t(r), maps(r)
+    m_new.xm = ld4(P.xmapr + row_m);
+    m_new.ym = ld4(P.ymapr + row_m);
+    if (!TFP) {
+      m_new.fc = ld4(P.fcoriolis + row_m);
+      m_new.t = ld4(P.t + row_m);
+    }
+
+    // ---- stage A: intermediate row y = r-1, for every group the wave holds (halo groups included)
+    const int y = r - 1;
+    if (loadable && y >= 1 && y <= ny - 2 && y >= jb0 - 1 && y <= jb1) {
+      const float* Sr = ringA + ((y - 1) % RA) * TS;
+      const float* Cr = ringA + (y % RA) * TS;
+      const float* Nr = ringA + ((y + 1) % RA) * TS;
+      float sv[4], nv[4], cv[6], xm[4], ym[4];
+      unpack(ld4(Sr + p), sv);
+      unpack(ld4(Nr + p), nv);
+      row6(Cr, p, cv);
+      unpack(m_a.xm, xm);
+      unpack(m_a.ym, ym);
+      if (TFP) {
+        const bool counted = CHECK && owned && y >= jb0 && y < jb1; // every cell is counted by the wave that owns it
+        float g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bool ok;
+          g[k] = tfp_absdelt<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], undef, ok);
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3); // counted by edge_count_cells
+          if (counted && !edge_cell && !ok)
+            ++n1;
+        }
+        if (fill_w)
+          g[0] = g[1];
+        if (fill_e)
+          g[3] = g[2];
+        st4(mid0 + (y % 3) * TS + p, g);
+      } else {
+        float fc[4], ug[4], vg[4];
+        unpack(m_a.fc, fc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          qvec_gwind<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], fc[k], undef, ug[k], vg[k]);
+        if (fill_w) {
+          ug[0] = ug[1];
+          vg[0] = vg[1];
+        }
+        if (fill_e) {
+          ug[3] = ug[2];
+          vg[3] = vg[2];
+        }
+        st4(mid0 + (y % 3) * TS + p, ug);
+        st4(mid1 + (y % 3) * TS + p, vg);
+      }
+    }
+
+    // ---- stage B: result row j = r-2, owned groups
+    const int j = r - 2;
+    const bool have_row = owned && j >= jb0 && j < jb1;
+    // Q-vector: x-neighbours of the temperature row j from the adjacent lanes (all lanes active here)
+    float t_west = 0.f, t_east = 0.f;
+    if (!TFP) {
+      const float tx_first = m_b.t.x, tx_last = m_b.t.w;
+      t_west = from_lower_lane(0.f, tx_last);
+      t_east = from_upper_lane(0.f, tx_first);
+    }
+    float o[4] = {undef, undef, undef, undef};
+    if (have_row) {
+      const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > ny - 2) ? ny - 2 : j + 1; // filled intermediate rows 0 / ny-1 are rows 1 / ny-2
+      float xm[4], ym[4];
+      unpack(m_b.xm, xm);
+      unpack(m_b.ym, ym);
+      if (TFP) {
+        float gs[4], gn[4], gc[6], ts[4], tn[4], tc[6];
+        unpack(ld4(mid0 + (js % 3) * TS + p), gs);
+        unpack(ld4(mid0 + (jn % 3) * TS + p), gn);
+        row6(mid0 + (j % 3) * TS, p, gc);
+        unpack(ld4(ringA + ((j - 1) % RA) * TS + p), ts);
+        unpack(ld4(ringA + ((j + 1) % RA) * TS + p), tn);
+        row6(ringA + (j % RA) * TS, p, tc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bool ok, by_test;
+          o[k] = tfp_point<CHECK>(ts[k], tc[k], tc[k + 2], tn[k], gs[k], gc[k], gc[k + 1], gc[k + 2], gn[k], xm[k], ym[k], undef, ok, by_test);
+          // the cells of columns 0 / nx-1 need wrapped neighbours for their tests: the edge kernel counts
+          // them -- unless nothing is tested, then |grad| != 0 of the filled value is all there is
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
+          if (!(CHECK && edge_cell)) {
+            n2 += ok ? 0u : 1u;
+            if (by_test)
+              ++n2c;
+          }
+        }
+      } else {
+        float us[4], un[4], uc[6], vs[4], vn[4], vc[6], ts[4], tn[4], tc[6];
+        unpack(ld4(mid0 + (js % 3) * TS + p), us);
+        unpack(ld4(mid0 + (jn % 3) * TS + p), un);
+        row6(mid0 + (j % 3) * TS, p, uc);
+        unpack(ld4(mid1 + (js % 3) * TS + p), vs);
+        unpack(ld4(mid1 + (jn % 3) * TS + p), vn);
+        row6(mid1 + (j % 3) * TS, p, vc);
+        unpack(t_south, ts);
+        unpack(m_a.t, tn);
+        tc[0] = t_west;
+        tc[1] = m_b.t.x;
+        tc[2] = m_b.t.y;
+        tc[3] = m_b.t.z;
+        tc[4] = m_b.t.w;
+        tc[5] = t_east;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bool ok;
+          o[k] = qvec_point<OP>(us[k], uc[k], uc[k + 2], un[k], vs[k], vc[k], vc[k + 2], vn[k], ts[k], tc[k], tc[k + 2], tn[k], xm[k], ym[k], P.scale,
+                                P.scale2, undef, ok);
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
+          if (!edge_cell)
+            n2 += ok ? 0u : 1u;
+        }
+      }
+      // fillEdges on the result: columns, then rows 0 / ny-1
+      if (fill_w)
+        o[0] = o[1];
+      if (fill_e)
+        o[3] = o[2];
+    }
+    // rows that were in flight since the top of the iteration; the explicit vmcnt(0) (all paths,
+    // loads only by now) keeps the compiler from waiting again -- behind the store -- at the loop edge
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (loadable) {
+      if (load_a)
+        *reinterpret_cast<float4*>(ringA + ((r + 1) % RA) * TS + p) = pa;
+    }
+    if (!TFP)
+      t_south = m_b.t; // row r-2 is row (r+1)-3
+    if (have_row) {
+      const v4f q = {o[0], o[1], o[2], o[3]};
+      __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)j * nx + xq));
+      if (j == 1)
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + xq));
+      if (j == ny - 2)
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)(ny - 1) * nx + xq));
+    }
+  };
+  for (int r = rs; r <= re; r += 3) {
+    iteration(r, m0, m2, m1);
+    if (r + 1 > re)
+      break;
+    iteration(r + 1, m1, m0, m2);
+    if (r + 2 > re)
+      break;
+    iteration(r + 2, m2, m1, m0);
+  }
+  if (TFP && CHECK) {
+    wave_count_add(P.counts + 0, n1);
+    wave_count_add(P.counts + 2, n2c);
+  }
+  wave_count_add(P.counts + 1, n2);
+}
+
+// TFP with a tested input: its edge cells as a launch of their own (inlined behind the tiles like the
+// Q-vector's, the two code paths together spill registers)
+template <int OP, bool CHECK>
+__global__ __launch_bounds__(256) void fused2_edge_count_kernel(const Fused2Params P)
+{
+  edge_count_cells<OP, CHECK>(P, (int)(blockIdx.x * 256 + threadIdx.x), (int)gridDim.x * 256);
+}
+
 template <int OP, bool CHECK>
 hipError_t launch(const Fused2Params& p, hipStream_t stream)
 {
@@ -395,12 +445,19 @@ hipError_t launch(const Fused2Params& p, hipStream_t stream)
     if (std::atoi(e) > 0)
       band = std::atoi(e);
   const int nbands = (interior + band - 1) / band;
-  hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(nbands * ntiles)), dim3(64), 0, stream, p, band, ntiles);
+  const int n_main = nbands * ntiles;
+  int n_edge = 0; // TFP with an ALL_DEFINED input counts its edge cells in the tiles (nothing wrapped is tested)
   if (OP != F2_TFP || CHECK) {
-    int g = (2 * interior + 255) / 256;
-    if (g > 1024)
-      g = 1024;
-    hipLaunchKernelGGL((fused2_edge_count_kernel<OP, CHECK>), dim3((unsigned)g), dim3(256), 0, stream, p);
+    n_edge = (2 * interior + 63) / 64;
+    if (n_edge > 256)
+      n_edge = 256;
+  }
+  if (OP == F2_TFP) {
+    hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)n_main), dim3(64), 0, stream, p, band, ntiles, n_main);
+    if (n_edge > 0)
+      hipLaunchKernelGGL((fused2_edge_count_kernel<OP, CHECK>), dim3((unsigned)((n_edge + 3) / 4)), dim3(256), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(n_main + n_edge)), dim3(64), 0, stream, p, band, ntiles, n_main);
   }
   return hipGetLastError();
 }
