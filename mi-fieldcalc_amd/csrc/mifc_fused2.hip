@@ -7,27 +7,39 @@
 //       ug = plevelgwind_xcomp(z), vg = plevelgwind_ycomp(z), edges filled;
 //       qcomp = f(ug, vg, t)
 // Run as separate launches the intermediate fields cost a write and five reads
-// of HBM/L2 each.  Here a workgroup spans the whole row width and walks down a
-// band of rows; the source rows and the intermediate rows it needs sit in LDS
-// row rings, so every field is read from HBM once (plus the band's halo rows)
-// and only the result is written:
+// of HBM/L2 each.  Here a WAVE (one per workgroup) owns a tile of 240 columns
+// and walks down a band of rows; the source rows and the edge-filled
+// intermediate rows it needs sit in LDS row rings (1 KiB per row), so every
+// field is read from HBM once (plus halo rows / columns) and only the result is
+// written:
 //
-//   iteration r:  top      issue the global loads of source row r+1 and of
-//                          map-factor row r (registers)
+//   iteration r:  top      issue the global loads of source row r+1, of
+//                          map-factor row r and (Q-vector) temperature row r
 //                 stage A  intermediate row r-1 from source rows r-2..r -> ring M
 //                 stage B  result row r-2 from intermediate rows r-3..r-1
 //                          (and source/temperature rows r-3..r-1)
 //                 end      the loaded source row lands in ring A; store row r-2
+//
+// A wave owns 60 float4 column groups and loads one more on either side, so the
+// x-neighbours of its intermediate rows are its own: nothing is shared between
+// waves and there is no barrier at all -- the LDS queue of a wave is in order.
+// (A first version had one workgroup span the whole row width; it spent half
+// its time or more at its two barriers per row: profiles/r01/valu_by_kernel.txt.)
 //
 // Reference semantics kept (mifc_stencil.hip header): every pass is a flat loop
 // over rows 1..ny-2 whose edge-column cells see neighbours wrapped into the
 // adjacent row and take part in the count; fillEdges then makes
 // final(j,i) = raw(clamp(j,1,ny-2), clamp(i,1,nx-2)) -- for the intermediate
 // fields as well, which is why ring M holds FILLED rows and rows 0 / ny-1 alias
-// rows 1 / ny-2.
+// rows 1 / ny-2.  What a tile cannot see is the far edge of the field: the
+// VALUES of columns 0 and nx-1 are fill copies of columns 1 / nx-2, which the
+// edge tiles own; their share of the undefined COUNT is taken by a few extra
+// workgroups (edge_count_cells below), two cells per row straight from global
+// memory.  (TFP with an ALL_DEFINED input needs no wrapped neighbour for the
+// count -- only |grad| != 0 -- and has no such workgroups.)
 //
-// Requirements (fused2_supported): nx % 4 == 0, nx <= 4096, 16-byte aligned
-// fields, rings fit the 160 KiB of LDS.  Everything else takes the multi-pass path.
+// Requirements (fused2_supported): nx % 4 == 0 and 16-byte aligned fields.
+// Everything else takes the multi-pass path.
 #include <cstdlib>
 
 #include "mifc_device.h"
@@ -39,14 +51,9 @@ namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int F2_PAD = 4; // floats in front of / behind every LDS row: keeps rows 16-byte aligned, and x0-1 / x0+4 in bounds
-
-// LDS-only barrier: the register prefetch of the next source row stays in flight
-// across it (a __syncthreads() would wait for vmcnt(0) as well)
-__device__ __forceinline__ void lds_barrier()
-{
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
+constexpr int TW = 240;       // cells a tile owns per row
+constexpr int TS = TW + 16;   // floats per LDS row: 4 pad | halo quad | 60 owned quads | halo quad | 4 pad
+constexpr int TQ = TW / 4 + 2; // column groups a wave holds (62 of its 64 lanes)
 
 __device__ __forceinline__ float4 ld4(const float* p)
 {
@@ -63,148 +70,290 @@ __device__ __forceinline__ void unpack(const float4 q, float (&v)[4])
   v[2] = q.z;
   v[3] = q.w;
 }
-// {west, own four, east} of a row in LDS; the edge threads take the neighbour the
-// reference's flat loop sees there: (nx-1, j-1) left of column 0, (0, j+1) right of column nx-1
-__device__ __forceinline__ void row6(const float* south, const float* centre, const float* north, int x0, int nx, bool first, bool last, float (&v)[6])
+// lane i <- lane i-1 / lane i+1 (wave shifts; the edge lane keeps `keep_if_none`).  Every lane of the
+// wave must be active where these are called: a disabled source lane leaves the destination unchanged.
+__device__ __forceinline__ float from_lower_lane(float keep_if_none, float x)
 {
-  const float4 q = ld4(centre + x0);
-  v[0] = first ? south[nx - 1] : centre[x0 - 1];
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float from_upper_lane(float keep_if_none, float x)
+{
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
+// {west, own four, east} of a ring row
+__device__ __forceinline__ void row6(const float* row, int p, float (&v)[6])
+{
+  const float4 q = ld4(row + p);
+  v[0] = row[p - 1];
   v[1] = q.x;
   v[2] = q.y;
   v[3] = q.z;
   v[4] = q.w;
-  v[5] = last ? north[0] : centre[x0 + 4];
+  v[5] = row[p + 4];
 }
 
+// ---- the point formulas, shared with the edge-count kernel
+// gradient compute 3, FieldCalculations.cc:2037-2046
+template <bool CHECK>
+__device__ __forceinline__ float tfp_absdelt(float s, float w, float e, float n, float xm, float ym, float undef, bool& ok)
+{
+  ok = !CHECK || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef));
+  const float dfdx = (float)(0.5 * (double)xm * (double)(e - w));
+  const float dfdy = (float)(0.5 * (double)ym * (double)(n - s));
+  return ok ? absval(dfdx, dfdy) : undef;
+}
+// plevelgwind_xcomp :660-663 (tests only if the caller's flag is not ALL_DEFINED),
+// plevelgwind_ycomp :693-698 (always tests: the x pass hands it NONE_DEFINED, :664)
+template <bool CHECK>
+__device__ __forceinline__ void qvec_gwind(float s, float w, float e, float n, float xm, float ym, float fc, float undef, float& ug, float& vg)
+{
+  const bool ok = is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef);
+  const double fd = (double)fc, finv = shared_reciprocal(fd);
+  const float u = (float)quotient(-0.5 * (double)ym * (double)(n - s) * (double)MIFC_K_G, fd, finv);
+  const float v = (float)quotient(0.5 * (double)xm * (double)(e - w) * (double)MIFC_K_G, fd, finv);
+  ug = (!CHECK || ok) ? u : undef;
+  vg = ok ? v : undef;
+}
+// thermalFrontParameter :2290-2298
+template <bool CHECK>
+__device__ __forceinline__ float tfp_point(float ts, float tw, float te, float tn, float gs, float gw, float g, float ge, float gn, float xm, float ym,
+                                           float undef, bool& ok, bool& rejected_by_test_only)
+{
+  const bool def = !CHECK || (is_def(ts, undef) && is_def(tw, undef) && is_def(te, undef) && is_def(tn, undef) && is_def(gs, undef) &&
+                              is_def(gw, undef) && is_def(g, undef) && is_def(ge, undef) && is_def(gn, undef));
+  ok = def && g != 0;
+  rejected_by_test_only = CHECK && !def && g != 0;
+  const double hx = 0.5 * (double)xm, hy = 0.5 * (double)ym;
+  const float dabsdeltdx = (float)(hx * (double)(ge - gw));
+  const float dabsdeltdy = (float)(hy * (double)(gn - gs));
+  const double gd = (double)g, ginv = shared_reciprocal(gd);
+  const float dtdxa = (float)quotient(hx * (double)(te - tw), gd, ginv);
+  const float dtdya = (float)quotient(hy * (double)(tn - ts), gd, ginv);
+  return ok ? -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya) : undef;
+}
+// plevelqvector :570-584, "!= undef" only
+template <int OP>
+__device__ __forceinline__ float qvec_point(float us, float uw, float ue, float un, float vs, float vw, float ve, float vn, float ts, float tw, float te,
+                                            float tn, float xm, float ym, float scale, float scale2, float undef, bool& ok)
+{
+  ok = us != undef && uw != undef && ue != undef && un != undef && vs != undef && vw != undef && ve != undef && vn != undef && ts != undef &&
+       tw != undef && te != undef && tn != undef;
+  const double hx = 0.5 * (double)xm, hy = 0.5 * (double)ym;
+  const float dtdx = (float)(hx * (double)scale * (double)(te - tw));
+  const float dtdy = (float)(hy * (double)scale * (double)(tn - ts));
+  float q;
+  if (OP == F2_QVEC_X) {
+    const float dugdx = (float)(hx * (double)(ue - uw));
+    const float dvgdx = (float)(hx * (double)(ve - vw));
+    q = scale2 * (dugdx * dtdx + dvgdx * dtdy);
+  } else {
+    const float dugdy = (float)(hy * (double)(un - us));
+    const float dvgdy = (float)(hy * (double)(vn - vs));
+    q = scale2 * (dugdy * dtdx + dvgdy * dtdy);
+  }
+  return ok ? q : undef;
+}
+
+// |grad tx| after its fillEdges: the raw value at the clamped position (always an interior cell), from
+// global memory.  Out of line on purpose: five of these inlined into one edge cell made the compiler
+// spill a thousand scalar registers; the edge cells are 2 per row, a call costs nothing that matters.
+template <bool CHECK>
+__device__ __attribute__((noinline)) float absdelt_filled_at(const Fused2Params& P, int x, int y)
+{
+  const int nx = P.nx;
+  x = x < 1 ? 1 : (x > nx - 2 ? nx - 2 : x);
+  y = y < 1 ? 1 : (y > P.ny - 2 ? P.ny - 2 : y);
+  const size_t c = (size_t)y * nx + x;
+  bool ok;
+  return tfp_absdelt<CHECK>(P.a[c - nx], P.a[c - 1], P.a[c + 1], P.a[c + nx], P.xmapr[c], P.ymapr[c], P.undef, ok);
+}
+
+// The cells of columns 0 and nx-1, rows 1..ny-2: only their contribution to the counts (their values
+// are fill copies).  Run by a few extra workgroups at the end of the grid (Q-vector) or a small launch
+// of their own (TFP with a tested input); lane = (row, side); everything comes from global memory, with the neighbours the
+// flat loop of the reference sees: west of column 0 is (nx-1, j-1), east of column nx-1 is (0, j+1).
 template <int OP, bool CHECK>
-__global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, const int band)
+__device__ __forceinline__ void edge_count_cells(const Fused2Params& P, const int first, const int stride)
 {
   constexpr bool TFP = OP == F2_TFP;
-  constexpr int RA = TFP ? 5 : 3; // TFP reads its source rows in stage B too (see hazards below)
-  extern __shared__ float4 lds4[];
   const int nx = P.nx, ny = P.ny;
-  const int S = nx + 2 * F2_PAD;
-  float* ringA = reinterpret_cast<float*>(lds4) + F2_PAD; // source rows: tx | z
-  float* ringT = ringA + RA * S;                          // Q-vector: temperature rows (4)
-  float* mid0 = ringT + (TFP ? 0 : 4 * S);                // |grad tx| | ug, filled (3)
-  float* mid1 = mid0 + 3 * S;                             // Q-vector: vg, filled (3)
+  const float undef = P.undef;
+  auto at = [&](const float* f, int x, int y) { return f[(size_t)y * nx + x]; };
+  auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+  // intermediate fields after their fillEdges: the raw value at the clamped position (always an interior cell)
+  auto absdelt_filled = [&](int x, int y) { return absdelt_filled_at<CHECK>(P, x, y); };
+  auto gwind_filled = [&](int x, int y, float& ug, float& vg) {
+    x = clampi(x, 1, nx - 2);
+    y = clampi(y, 1, ny - 2);
+    qvec_gwind<CHECK>(at(P.a, x, y - 1), at(P.a, x - 1, y), at(P.a, x + 1, y), at(P.a, x, y + 1), at(P.xmapr, x, y), at(P.ymapr, x, y),
+                      at(P.fcoriolis, x, y), undef, ug, vg);
+  };
+  unsigned int n1 = 0, n2 = 0, n2c = 0;
+  const int cells = 2 * (ny - 2);
+  for (int i = first; i < cells; i += stride) {
+    const int j = 1 + (i >> 1);
+    const bool left = (i & 1) == 0;
+    const int x = left ? 0 : nx - 1;
+    // flat-index neighbours
+    const int wx = left ? nx - 1 : nx - 2, wy = left ? j - 1 : j;
+    const int ex = left ? 1 : 0, ey = left ? j : j + 1;
+    if (TFP) {
+      const float ts = at(P.a, x, j - 1), tw = at(P.a, wx, wy), te = at(P.a, ex, ey), tn = at(P.a, x, j + 1);
+      if (CHECK && !(is_def(ts, undef) && is_def(tw, undef) && is_def(te, undef) && is_def(tn, undef)))
+        ++n1; // gradient compute 3 :2039
+      bool ok, by_test;
+      (void)tfp_point<CHECK>(ts, tw, te, tn, absdelt_filled(x, j - 1), absdelt_filled(wx, wy), absdelt_filled(x, j), absdelt_filled(ex, ey),
+                             absdelt_filled(x, j + 1), at(P.xmapr, x, j), at(P.ymapr, x, j), undef, ok, by_test);
+      n2 += ok ? 0u : 1u;
+      if (by_test)
+        ++n2c;
+    } else {
+      float us, uw, ue, un, vs, vw, ve, vn;
+      gwind_filled(x, j - 1, us, vs);
+      gwind_filled(wx, wy, uw, vw);
+      gwind_filled(ex, ey, ue, ve);
+      gwind_filled(x, j + 1, un, vn);
+      bool ok;
+      (void)qvec_point<OP>(us, uw, ue, un, vs, vw, ve, vn, at(P.t, x, j - 1), at(P.t, wx, wy), at(P.t, ex, ey), at(P.t, x, j + 1), at(P.xmapr, x, j),
+                           at(P.ymapr, x, j), P.scale, P.scale2, undef, ok);
+      n2 += ok ? 0u : 1u;
+    }
+  }
+  if (TFP && CHECK) {
+    wave_count_add(P.counts + 0, n1);
+    wave_count_add(P.counts + 2, n2c);
+  }
+  wave_count_add(P.counts + 1, n2);
+}
 
-  const int c = threadIdx.x;
-  const int nq = nx >> 2;
-  const bool active = c < nq;
-  const bool first = c == 0, last = c == nq - 1;
-  const int x0 = c * 4;
+// Ring depths.  One wave reads and writes its rings in program order, so a row may be replaced as soon
+// as its last read has been ISSUED: source rows r-2..r+1 are live after iteration r for TFP (its last
+// stage reads rows r-3..r-1 of the source again), r-1..r+1 for the Q-vector; intermediate rows r-3..r-1.
+template <int OP, bool CHECK>
+__global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_tile_kernel(const Fused2Params P, const int band, const int ntiles, const int n_main)
+{
+  constexpr bool TFP = OP == F2_TFP;
+  if (!TFP && (int)blockIdx.x >= n_main) { // Q-vector: the workgroups behind the tiles count the edge-column cells
+    edge_count_cells<OP, CHECK>(P, ((int)blockIdx.x - n_main) * 64 + (int)threadIdx.x, ((int)gridDim.x - n_main) * 64);
+    return;
+  }
+  constexpr int RA = TFP ? 4 : 3;
+  constexpr int ROWS = TFP ? RA + 3 : RA + 3 + 3;
+  __shared__ float4 lds4[ROWS * TS / 4];
+  float* ringA = reinterpret_cast<float*>(lds4); // source rows: tx | z
+  float* mid0 = ringA + RA * TS;                 // |grad tx| | ug, edge-filled (3)
+  float* mid1 = mid0 + 3 * TS;                   // Q-vector: vg, edge-filled (3)
+  // The Q-vector's temperature rows stay in registers (three rows of the lane's own column group; the
+  // x-neighbours of the middle one come from the adjacent lanes): 9 instead of 12 KiB of LDS per wave
+  // is the difference between 13 and 16 waves on a CU.
+
+  const int nx = P.nx, ny = P.ny;
+  const int lane = threadIdx.x;
+  const int tile = (int)blockIdx.x % ntiles;
+  const int bidx = (int)blockIdx.x / ntiles;
+  const int xq = tile * TW - 4 + 4 * lane; // first column of this lane's group; lanes 0 and 61 hold the halo groups
+  const bool loadable = lane < TQ && xq >= 0 && xq < nx;
+  const bool owned = loadable && lane >= 1 && lane <= TW / 4;
+  const int p = 4 + 4 * lane;                 // position of the group in a ring row
+  const bool fill_w = xq == 0, fill_e = xq + 4 == nx; // the group holds column 0 / column nx-1 of the field
   const float undef = P.undef;
 
-  // rows 1..ny-2 are split into bands; rows 0 and ny-1 are written with rows 1 and ny-2
-  const int jb0 = 1 + (int)blockIdx.x * band;
+  const int jb0 = 1 + bidx * band;
   const int jb1 = (jb0 + band < ny - 1) ? jb0 + band : ny - 1;
   const int rs = jb0 - 2, re = jb1 + 1;
 
-  const size_t col = (size_t)x0;
-  const size_t ccol = active ? col : 0; // lanes beyond the row width load column 0 and use nothing
-  if (active && rs >= 0)
-    *reinterpret_cast<float4*>(ringA + (rs % RA) * S + x0) = ld4(P.a + (size_t)rs * nx + col);
+  const size_t ccol = (size_t)(loadable ? xq : tile * TW); // other lanes load a valid address and use nothing
+  if (loadable && rs >= 0)
+    *reinterpret_cast<float4*>(ringA + (rs % RA) * TS + p) = ld4(P.a + (size_t)rs * nx + ccol);
   unsigned int n1 = 0, n2 = 0, n2c = 0;
 
-  // Map-factor rows live in registers from the iteration that loads them (r) through stage A
-  // (r+1) to stage B (r+2): three sets, rotated by unrolling the row loop three times.
-  struct RowMaps
+  struct RowMaps // what a lane keeps of a row beyond the iteration that loads it: map factors, and the Q-vector's temperature
   {
-    float4 xm, ym, fc;
+    float4 xm, ym, fc, t;
   };
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  RowMaps m0 = {zero4, zero4, zero4}, m1 = m0, m2 = m0;
+  RowMaps m0 = {zero4, zero4, zero4, zero4}, m1 = m0, m2 = m0;
+  float4 t_south = zero4; // temperature row r-3
 
-  // One iteration.  Global loads are issued at the top and land in LDS at the end, just before
-  // the result row is stored: the wait there covers loads only (the previous store is a whole
-  // iteration old), and the store gets the next iteration to drain.
-  // LDS hazards, with the two barriers per iteration:
-  //   ring A, TFP (5): row r+1 written at the end replaces row r-4, last read by stage B of iteration r-1
-  //   ring A, Q-vector (3): replaces row r-2, last read by stage A of this iteration (before its second barrier)
-  //   ring T (4): row r written at the end replaces row r-4, last read by stage B of iteration r-1
-  //   ring M (3): row r-1 written in stage A replaces row r-4, last read by stage B of iteration r-1 (before this iteration's first barrier)
+  // One iteration (pipeline: file header; ring depths: above).  Global loads are issued at the top and
+  // land in LDS at the end, just before the result row is stored: the wait there covers loads only (the
+  // previous store is a whole iteration old), and the store gets the next iteration to drain.  The
+  // loads are unconditional (row and column clamped into the field): a load under a condition would
+  // make the compiler merge old and new register contents right there, i.e. wait for it.  Map rows are
+  // live for three iterations (load, stage A, stage B): three register sets, rotated by unrolling the
+  // row loop three times instead of by moves.
   auto iteration = [&](const int r, RowMaps& m_new /* row r */, const RowMaps& m_a /* row r-1 */, const RowMaps& m_b /* row r-2 */)
                        __attribute__((always_inline)) {
-    // Unconditional loads (row and column clamped into the field): a load under a condition
-    // would make the compiler merge old and new register contents right here, i.e. wait for it.
     const bool load_a = r < re && r + 1 >= 0 && r + 1 < ny;
-    const bool load_row = r < re && r >= 0 && r < ny;
     const size_t row_a = (size_t)(r + 1 < 0 ? 0 : (r + 1 > ny - 1 ? ny - 1 : r + 1)) * nx + ccol;
     const size_t row_m = (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + ccol;
-    const float4 pa = ld4(P.a + row_a); // in flight: A(r+1), t(r), maps(r)
-    float4 pt = zero4;
+    const float4 pa = ld4(P.a + row_a); // in flight until the end of the iteration: A(r+1), t(r), maps(r)
     m_new.xm = ld4(P.xmapr + row_m);
     m_new.ym = ld4(P.ymapr + row_m);
     if (!TFP) {
       m_new.fc = ld4(P.fcoriolis + row_m);
-      pt = ld4(P.t + row_m);
+      m_new.t = ld4(P.t + row_m);
     }
-    lds_barrier();
 
-    // ---- stage A: intermediate row y = r-1
+    // ---- stage A: intermediate row y = r-1, for every group the wave holds (halo groups included)
     const int y = r - 1;
-    if (active && y >= 1 && y <= ny - 2 && y >= jb0 - 1 && y <= jb1) {
-      const float* Sr = ringA + ((y - 1) % RA) * S;
-      const float* Cr = ringA + (y % RA) * S;
-      const float* Nr = ringA + ((y + 1) % RA) * S;
+    if (loadable && y >= 1 && y <= ny - 2 && y >= jb0 - 1 && y <= jb1) {
+      const float* Sr = ringA + ((y - 1) % RA) * TS;
+      const float* Cr = ringA + (y % RA) * TS;
+      const float* Nr = ringA + ((y + 1) % RA) * TS;
       float sv[4], nv[4], cv[6], xm[4], ym[4];
-      unpack(ld4(Sr + x0), sv);
-      unpack(ld4(Nr + x0), nv);
-      row6(Sr, Cr, Nr, x0, nx, first, last, cv);
+      unpack(ld4(Sr + p), sv);
+      unpack(ld4(Nr + p), nv);
+      row6(Cr, p, cv);
       unpack(m_a.xm, xm);
       unpack(m_a.ym, ym);
       if (TFP) {
-        // gradient compute 3, :2037-2046
-        const bool counted = CHECK && y >= jb0 && y < jb1; // every row is counted by the band that owns it
+        const bool counted = CHECK && owned && y >= jb0 && y < jb1; // every cell is counted by the wave that owns it
         float g[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float s = sv[k], n = nv[k], w = cv[k], e = cv[k + 2];
-          const bool ok = !CHECK || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef));
-          const float dfdx = (float)(0.5 * (double)xm[k] * (double)(e - w));
-          const float dfdy = (float)(0.5 * (double)ym[k] * (double)(n - s));
-          g[k] = ok ? absval(dfdx, dfdy) : undef;
-          if (counted && !ok)
+          bool ok;
+          g[k] = tfp_absdelt<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], undef, ok);
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3); // counted by edge_count_cells
+          if (counted && !edge_cell && !ok)
             ++n1;
         }
-        if (first)
+        if (fill_w)
           g[0] = g[1];
-        if (last)
+        if (fill_e)
           g[3] = g[2];
-        st4(mid0 + (y % 3) * S + x0, g);
+        st4(mid0 + (y % 3) * TS + p, g);
       } else {
-        // plevelgwind_xcomp :660-663 (tests only if the caller's flag is not ALL_DEFINED),
-        // plevelgwind_ycomp :693-698 (always tests: the x pass hands it NONE_DEFINED, :664)
         float fc[4], ug[4], vg[4];
         unpack(m_a.fc, fc);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float s = sv[k], n = nv[k], w = cv[k], e = cv[k + 2];
-          const bool ok = is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef);
-          const double fd = (double)fc[k], finv = shared_reciprocal(fd);
-          const float u = (float)quotient(-0.5 * (double)ym[k] * (double)(n - s) * (double)MIFC_K_G, fd, finv);
-          const float v = (float)quotient(0.5 * (double)xm[k] * (double)(e - w) * (double)MIFC_K_G, fd, finv);
-          ug[k] = (!CHECK || ok) ? u : undef;
-          vg[k] = ok ? v : undef;
-        }
-        if (first) {
+        for (int k = 0; k < 4; ++k)
+          qvec_gwind<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], fc[k], undef, ug[k], vg[k]);
+        if (fill_w) {
           ug[0] = ug[1];
           vg[0] = vg[1];
         }
-        if (last) {
+        if (fill_e) {
           ug[3] = ug[2];
           vg[3] = vg[2];
         }
-        st4(mid0 + (y % 3) * S + x0, ug);
-        st4(mid1 + (y % 3) * S + x0, vg);
+        st4(mid0 + (y % 3) * TS + p, ug);
+        st4(mid1 + (y % 3) * TS + p, vg);
       }
     }
-    lds_barrier();
 
-    // ---- stage B: result row j = r-2
+    // ---- stage B: result row j = r-2, owned groups
     const int j = r - 2;
-    const bool have_row = active && j >= jb0 && j < jb1;
+    const bool have_row = owned && j >= jb0 && j < jb1;
+    // Q-vector: x-neighbours of the temperature row j from the adjacent lanes (all lanes active here)
+    float t_west = 0.f, t_east = 0.f;
+    if (!TFP) {
+      const float tx_first = m_b.t.x, tx_last = m_b.t.w;
+      t_west = from_lower_lane(0.f, tx_last);
+      t_east = from_upper_lane(0.f, tx_first);
+    }
     float o[4] = {undef, undef, undef, undef};
     if (have_row) {
       const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > ny - 2) ? ny - 2 : j + 1; // filled intermediate rows 0 / ny-1 are rows 1 / ny-2
@@ -212,102 +361,74 @@ __global__ __launch_bounds__(1024) void fused2_kernel(const Fused2Params P, cons
       unpack(m_b.xm, xm);
       unpack(m_b.ym, ym);
       if (TFP) {
-        const float* Gs = mid0 + (js % 3) * S;
-        const float* Gc = mid0 + (j % 3) * S;
-        const float* Gn = mid0 + (jn % 3) * S;
-        const float* Ts = ringA + ((j - 1) % RA) * S;
-        const float* Tc = ringA + (j % RA) * S;
-        const float* Tn = ringA + ((j + 1) % RA) * S;
         float gs[4], gn[4], gc[6], ts[4], tn[4], tc[6];
-        unpack(ld4(Gs + x0), gs);
-        unpack(ld4(Gn + x0), gn);
-        row6(Gs, Gc, Gn, x0, nx, first, last, gc);
-        unpack(ld4(Ts + x0), ts);
-        unpack(ld4(Tn + x0), tn);
-        row6(Ts, Tc, Tn, x0, nx, first, last, tc);
+        unpack(ld4(mid0 + (js % 3) * TS + p), gs);
+        unpack(ld4(mid0 + (jn % 3) * TS + p), gn);
+        row6(mid0 + (j % 3) * TS, p, gc);
+        unpack(ld4(ringA + ((j - 1) % RA) * TS + p), ts);
+        unpack(ld4(ringA + ((j + 1) % RA) * TS + p), tn);
+        row6(ringA + (j % RA) * TS, p, tc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          // :2290-2298
-          const float g = gc[k + 1];
-          const bool def = !CHECK || (is_def(ts[k], undef) && is_def(tc[k], undef) && is_def(tc[k + 2], undef) && is_def(tn[k], undef) &&
-                                      is_def(gs[k], undef) && is_def(gc[k], undef) && is_def(g, undef) && is_def(gc[k + 2], undef) && is_def(gn[k], undef));
-          const bool ok = def && g != 0;
-          const double hx = 0.5 * (double)xm[k], hy = 0.5 * (double)ym[k];
-          const float dabsdeltdx = (float)(hx * (double)(gc[k + 2] - gc[k]));
-          const float dabsdeltdy = (float)(hy * (double)(gn[k] - gs[k]));
-          const double gd = (double)g, ginv = shared_reciprocal(gd);
-          const float dtdxa = (float)quotient(hx * (double)(tc[k + 2] - tc[k]), gd, ginv);
-          const float dtdya = (float)quotient(hy * (double)(tn[k] - ts[k]), gd, ginv);
-          o[k] = ok ? -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya) : undef;
-          n2 += ok ? 0u : 1u;
-          if (CHECK && !def && g != 0)
-            ++n2c;
+          bool ok, by_test;
+          o[k] = tfp_point<CHECK>(ts[k], tc[k], tc[k + 2], tn[k], gs[k], gc[k], gc[k + 1], gc[k + 2], gn[k], xm[k], ym[k], undef, ok, by_test);
+          // the cells of columns 0 / nx-1 need wrapped neighbours for their tests: the edge kernel counts
+          // them -- unless nothing is tested, then |grad| != 0 of the filled value is all there is
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
+          if (!(CHECK && edge_cell)) {
+            n2 += ok ? 0u : 1u;
+            if (by_test)
+              ++n2c;
+          }
         }
       } else {
-        const float* Us = mid0 + (js % 3) * S;
-        const float* Uc = mid0 + (j % 3) * S;
-        const float* Un = mid0 + (jn % 3) * S;
-        const float* Vs = mid1 + (js % 3) * S;
-        const float* Vc = mid1 + (j % 3) * S;
-        const float* Vn = mid1 + (jn % 3) * S;
-        const float* Ts = ringT + ((j - 1) % 4) * S;
-        const float* Tc = ringT + (j % 4) * S;
-        const float* Tn = ringT + ((j + 1) % 4) * S;
         float us[4], un[4], uc[6], vs[4], vn[4], vc[6], ts[4], tn[4], tc[6];
-        unpack(ld4(Us + x0), us);
-        unpack(ld4(Un + x0), un);
-        row6(Us, Uc, Un, x0, nx, first, last, uc);
-        unpack(ld4(Vs + x0), vs);
-        unpack(ld4(Vn + x0), vn);
-        row6(Vs, Vc, Vn, x0, nx, first, last, vc);
-        unpack(ld4(Ts + x0), ts);
-        unpack(ld4(Tn + x0), tn);
-        row6(Ts, Tc, Tn, x0, nx, first, last, tc);
+        unpack(ld4(mid0 + (js % 3) * TS + p), us);
+        unpack(ld4(mid0 + (jn % 3) * TS + p), un);
+        row6(mid0 + (j % 3) * TS, p, uc);
+        unpack(ld4(mid1 + (js % 3) * TS + p), vs);
+        unpack(ld4(mid1 + (jn % 3) * TS + p), vn);
+        row6(mid1 + (j % 3) * TS, p, vc);
+        unpack(t_south, ts);
+        unpack(m_a.t, tn);
+        tc[0] = t_west;
+        tc[1] = m_b.t.x;
+        tc[2] = m_b.t.y;
+        tc[3] = m_b.t.z;
+        tc[4] = m_b.t.w;
+        tc[5] = t_east;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          // :570-584, "!= undef" only
-          const bool ok = us[k] != undef && uc[k] != undef && uc[k + 2] != undef && un[k] != undef && vs[k] != undef && vc[k] != undef &&
-                          vc[k + 2] != undef && vn[k] != undef && ts[k] != undef && tc[k] != undef && tc[k + 2] != undef && tn[k] != undef;
-          const double hx = 0.5 * (double)xm[k], hy = 0.5 * (double)ym[k];
-          const float dtdx = (float)(hx * (double)P.scale * (double)(tc[k + 2] - tc[k]));
-          const float dtdy = (float)(hy * (double)P.scale * (double)(tn[k] - ts[k]));
-          float q;
-          if (OP == F2_QVEC_X) {
-            const float dugdx = (float)(hx * (double)(uc[k + 2] - uc[k]));
-            const float dvgdx = (float)(hx * (double)(vc[k + 2] - vc[k]));
-            q = P.scale2 * (dugdx * dtdx + dvgdx * dtdy);
-          } else {
-            const float dugdy = (float)(hy * (double)(un[k] - us[k]));
-            const float dvgdy = (float)(hy * (double)(vn[k] - vs[k]));
-            q = P.scale2 * (dugdy * dtdx + dvgdy * dtdy);
-          }
-          o[k] = ok ? q : undef;
-          n2 += ok ? 0u : 1u;
+          bool ok;
+          o[k] = qvec_point<OP>(us[k], uc[k], uc[k + 2], un[k], vs[k], vc[k], vc[k + 2], vn[k], ts[k], tc[k], tc[k + 2], tn[k], xm[k], ym[k], P.scale,
+                                P.scale2, undef, ok);
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
+          if (!edge_cell)
+            n2 += ok ? 0u : 1u;
         }
       }
       // fillEdges on the result: columns, then rows 0 / ny-1
-      if (first)
+      if (fill_w)
         o[0] = o[1];
-      if (last)
+      if (fill_e)
         o[3] = o[2];
     }
     // rows that were in flight since the top of the iteration; the explicit vmcnt(0) (all paths,
     // loads only by now) keeps the compiler from waiting again -- behind the store -- at the loop edge
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    if (active) {
+    if (loadable) {
       if (load_a)
-        *reinterpret_cast<float4*>(ringA + ((r + 1) % RA) * S + x0) = pa;
-      if (!TFP && load_row)
-        *reinterpret_cast<float4*>(ringT + (r % 4) * S + x0) = pt;
+        *reinterpret_cast<float4*>(ringA + ((r + 1) % RA) * TS + p) = pa;
     }
+    if (!TFP)
+      t_south = m_b.t; // row r-2 is row (r+1)-3
     if (have_row) {
-      // the result is written once and never re-read here: nontemporal
       const v4f q = {o[0], o[1], o[2], o[3]};
-      __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)j * nx + col));
+      __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)j * nx + xq));
       if (j == 1)
-        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + col));
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + xq));
       if (j == ny - 2)
-        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)(ny - 1) * nx + col));
+        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)(ny - 1) * nx + xq));
     }
   };
   for (int r = rs; r <= re; r += 3) {
@@ -336,44 +457,50 @@ __global__ void division_check_kernel(const float* a, const float* b, const floa
   }
 }
 
-size_t lds_bytes(const Fused2Params& p)
+bool aligned16(const void* p)
 {
-  const size_t rows = p.op == F2_TFP ? 5 + 3 : 3 + 4 + 3 + 3;
-  return rows * (size_t)(p.nx + 2 * F2_PAD) * sizeof(float);
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
-constexpr size_t LDS_PER_CU = 160 * 1024;
+// TFP with a tested input: its edge cells as a launch of their own (inlined behind the tiles like the
+// Q-vector's, the two code paths together spill registers)
+template <int OP, bool CHECK>
+__global__ __launch_bounds__(256) void fused2_edge_count_kernel(const Fused2Params P)
+{
+  edge_count_cells<OP, CHECK>(P, (int)(blockIdx.x * 256 + threadIdx.x), (int)gridDim.x * 256);
+}
 
 template <int OP, bool CHECK>
 hipError_t launch(const Fused2Params& p, hipStream_t stream)
 {
-  const int threads = ((p.nx / 4 + 63) / 64) * 64;
-  const size_t lds = lds_bytes(p);
   const int interior = p.ny - 2;
-  // enough bands to fill the chip a few times over, tall enough that the
-  // 4 (source) + 2 (maps) halo rows a band re-reads stay a small fraction
-  size_t per_cu = LDS_PER_CU / lds;
-  if (per_cu * threads > 2048)
-    per_cu = 2048 / threads;
-  if (per_cu < 1)
-    per_cu = 1;
-  const long want_blocks = 256L * (long)per_cu * 4;
-  int band = (int)((interior + want_blocks - 1) / want_blocks);
-  if (band < 4) // one 1440x720 level: 4-row bands 16 / 20 us (TFP / Q-vector), 8-row bands 23 / 30 us, multi-pass 30 / 55 us
+  const int ntiles = (p.nx + TW - 1) / TW;
+  // enough workgroups to fill the chip several times over (16-20 single-wave workgroups fit a CU),
+  // bands tall enough that the 4 (source) + 2 (maps) halo rows a band re-reads stay a small fraction
+  const long want_bands = (256L * 16 * 4 + ntiles - 1) / ntiles;
+  int band = (int)((interior + want_bands - 1) / want_bands);
+  if (band < 4)
     band = 4;
   if (band > 64)
     band = 64;
   if (const char* e = std::getenv("MIFC_FUSED2_BAND")) // A/B measurements
     if (std::atoi(e) > 0)
       band = std::atoi(e);
-  const int blocks = (interior + band - 1) / band;
-  if (lds > 64 * 1024) {
-    const hipError_t e =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&fused2_kernel<OP, CHECK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess)
-      return e;
+  const int nbands = (interior + band - 1) / band;
+  const int n_main = nbands * ntiles;
+  int n_edge = 0; // TFP with an ALL_DEFINED input counts its edge cells in the tiles (nothing wrapped is tested)
+  if (OP != F2_TFP || CHECK) {
+    n_edge = (2 * interior + 63) / 64;
+    if (n_edge > 256)
+      n_edge = 256;
   }
-  hipLaunchKernelGGL((fused2_kernel<OP, CHECK>), dim3((unsigned)blocks), dim3((unsigned)threads), lds, stream, p, band);
+  if (OP == F2_TFP) {
+    hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)n_main), dim3(64), 0, stream, p, band, ntiles, n_main);
+    if (n_edge > 0)
+      hipLaunchKernelGGL((fused2_edge_count_kernel<OP, CHECK>), dim3((unsigned)((n_edge + 3) / 4)), dim3(256), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(n_main + n_edge)), dim3(64), 0, stream, p, band, ntiles, n_main);
+  }
   return hipGetLastError();
 }
 
@@ -381,11 +508,6 @@ template <int OP>
 hipError_t launch_op(const Fused2Params& p, hipStream_t stream)
 {
   return p.check ? launch<OP, true>(p, stream) : launch<OP, false>(p, stream);
-}
-
-bool aligned16(const void* p)
-{
-  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
 } // namespace
@@ -396,26 +518,12 @@ hipError_t launch_division_check(const float* a, const float* b, const float* g,
   return hipGetLastError();
 }
 
-// mifc_fused2_tile.hip: the same operators with one wave per workgroup and column tiles
-bool fused2_tile_supported(const Fused2Params& p);
-hipError_t launch_fused2_tile(const Fused2Params& p, hipStream_t stream);
-
-static bool tiles_enabled()
-{
-  const char* e = std::getenv("MIFC_FUSED2_TILE"); // "0": the row-wide kernel of this file (A/B measurements, tests)
-  return !(e && e[0] == '0');
-}
-
 bool fused2_supported(const Fused2Params& p)
 {
   if (p.nx < 4 || (p.nx & 3) || p.ny < 3)
     return false;
-  if (tiles_enabled()) {
-    if (!fused2_tile_supported(p))
-      return false;
-  } else if (p.nx > 4096 || lds_bytes(p) > LDS_PER_CU) {
+  if ((long)((p.nx + TW - 1) / TW) * ((p.ny - 2 + 3) / 4) + 256 >= 0x7fffffffL) // workgroups of the launch
     return false;
-  }
   if (!p.a || !p.xmapr || !p.ymapr || !p.out || !p.counts)
     return false;
   if (!aligned16(p.a) || !aligned16(p.xmapr) || !aligned16(p.ymapr) || !aligned16(p.out))
@@ -429,8 +537,6 @@ hipError_t launch_fused2(const Fused2Params& p, hipStream_t stream)
 {
   if (!fused2_supported(p))
     return hipErrorInvalidValue;
-  if (tiles_enabled())
-    return launch_fused2_tile(p, stream);
   switch (p.op) {
   case F2_TFP:
     return launch_op<F2_TFP>(p, stream);

@@ -76,11 +76,13 @@ def stencil_cases(grids=GRIDS_STENCIL, modes=MODES):
 
 def fused2_cases():
     """thermalFrontParameter / plevelqvector on grids the single-launch kernel takes (nx % 4 == 0):
-    one thread-quad wide, one band, many bands, the headline width; the usual flag modes plus
+    one column group wide, one band, many bands, the headline width; the usual flag modes plus
     the ones that matter to the pass-to-pass flag logic of the reference (:2286, :664)."""
     out = []
-    # ... and the widest rows the kernel takes: 1024 lanes (TFP), LDS-limited 3140 (Q-vector; 3144 falls back)
-    for nx, ny in [(4, 3), (4, 9), (8, 3), (12, 20), (64, 48), (128, 301), (1440, 37), (4096, 6), (3140, 11), (3144, 5)]:
+    # ... and widths around the 240-column tiles of the kernel: one partial tile, exactly one, one column
+    # group into the second, two and a bit, many
+    for nx, ny in [(4, 3), (4, 9), (8, 3), (12, 20), (64, 48), (128, 301), (236, 7), (240, 9), (244, 12), (484, 5), (1440, 37), (4096, 6),
+                   (5000, 4)]:
         xm, ym, fc = synth.grid_maps(nx, ny)
         seed = 31 * nx + ny
         z = synth.scalar_field(nx, ny, seed)
