@@ -365,7 +365,7 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   // gets shorter ones -- more waves on the chip, the halo re-reads stay in L2
   rp.R = 8;
   if (!std::getenv("MIFC_SCALAR_ROWS_R")) {
-    while (rp.R > 2 && (long)((prm.nlev + wpb - 1) / wpb) * ((ny - 2 + rp.R - 1) / rp.R) * rp.nwc < 2048)
+    while (rp.R > 2 && (long)prm.nlev * ((ny - 2 + rp.R - 1) / rp.R) * rp.nwc < 2048) // waves of the launch
       rp.R /= 2;
   } else if (std::atoi(std::getenv("MIFC_SCALAR_ROWS_R")) > 0) {
     rp.R = std::atoi(std::getenv("MIFC_SCALAR_ROWS_R")); // A/B measurements

@@ -827,9 +827,9 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   if (!std::getenv("MIFC_VORTDIV_TUNE")) {
     // A small launch (the reference's single-field call: one level) is latency-bound: shorter
     // bands put more waves on the chip, and their halo re-reads stay in L2.
-    // One 1440x720 level: 8-row bands 270 waves, 2-row bands 1077.
-    const long rows = prm.ny_local, wcols = (nx + 256 * t.V - 1) / (256 * t.V), groups = (prm.nlev + t.WPB - 1) / t.WPB;
-    while (t.R > 2 && groups * ((rows + t.R - 1) / t.R) * wcols < 2048)
+    // One 1440x720 level: 8-row bands 270 waves, 2-row bands 1077; 8 levels (a chunk of the host pipeline) keep 8.
+    const long rows = prm.ny_local, wcols = (nx + 256 * t.V - 1) / (256 * t.V), waves_per_band = (long)prm.nlev * wcols;
+    while (t.R > 2 && waves_per_band * ((rows + t.R - 1) / t.R) < 2048)
       t.R /= 2;
   }
   RowsParams rp;
