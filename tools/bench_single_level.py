@@ -71,6 +71,9 @@ for flag_name, flag in (("ALL_DEFINED", fc.ALL_DEFINED), ("SOME_DEFINED", fc.SOM
         ("pleveltemp c=3", lambda: ctx.pleveltemp(tk, 850.0, "kelvin", 3, fdefined=flag, out=out)),
         ("hlevelhum c=1", lambda: ctx.hlevelhum(tk, q, ps, 12.5, 0.73, "kelvin", 1, fdefined=flag, out=out)),
         ("jacobian", lambda: ctx.jacobian(z, u, dxm, dym, fdefined=flag, out=out)),
+        ("advection", lambda: ctx.advection(z, u, v, dxm, dym, 1.0, fdefined=flag, out=out)),
+        ("shapiro2_filter", lambda: ctx.shapiro2_filter(z, fdefined=flag, out=out)),
+        ("showalterIndex", lambda: ctx.showalterIndex(tk - 20.0, tk, q * 0 + 70.0, 500.0, 850.0, 1, fdefined=flag, out=out)),
     ]
     for name, fn in ops:
         print("%-34s %10.1f %10.1f" % (name + " (" + flag_name + ")", timed(fn), kernel_us(fn)))
