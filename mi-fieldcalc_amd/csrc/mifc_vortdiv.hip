@@ -669,6 +669,7 @@ struct Tuning
   int XH;    // measurement only: skip the halo rows (results are wrong), never set by the library itself
   int XS;    // measurement only: skip (practically all) stores
   int PADROWS; // measurement only: the last PADROWS rows of every level are padding (changes the level stride)
+  int LDSX;    // extra KiB of LDS requested per workgroup: limits the workgroups resident on a CU (occupancy experiments)
 };
 
 int tune_value(const char* s, const char* key, int dflt)
@@ -687,7 +688,7 @@ int tune_value(const char* s, const char* key, int dflt)
 
 Tuning current_tuning(int nx)
 {
-  Tuning t = {0, 8, 1, 1, 2, 1, 1, 8, 1, 0, 0, 0, 0}; // R = 6 / WPB = 4 run within 1 % of this but fetch more (halo rows, map factors): HBM traffic 1.13-1.14x vs 1.08x of the minimum
+  Tuning t = {0, 8, 1, 1, 2, 1, 1, 8, 1, 0, 0, 0, 0, 0}; // R = 6 / WPB = 4 run within 1 % of this but fetch more (halo rows, map factors): HBM traffic 1.13-1.14x vs 1.08x of the minimum
   // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,V=2,ORDER=1,XCD=1,WPB=8" -- used by the sweep tool and the tests
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     t.K = tune_value(s, "K", t.K);
@@ -700,6 +701,7 @@ Tuning current_tuning(int nx)
     t.WPB = tune_value(s, "WPB", t.WPB);
     t.ZZ = tune_value(s, "ZZ", t.ZZ);
     t.NTI = tune_value(s, "NTI", t.NTI);
+    t.LDSX = tune_value(s, "LDSX", t.LDSX);
     // knobs that make the kernel compute something else (wrong results by design) are only
     // honoured when the measurement tools say so explicitly
     if (std::getenv("MIFC_MEASUREMENT_KNOBS")) {
@@ -729,7 +731,7 @@ Tuning current_tuning(int nx)
 template <bool CHECK, bool WV, bool WD, bool ABSV, int D, bool NT>
 void launch_v(const RowsParams& rp, const Tuning& t, int grid, hipStream_t stream)
 {
-  const size_t lds = (size_t)rp.R * 1024 * t.V * (ABSV ? 3 : 2);
+  const size_t lds = (size_t)rp.R * 1024 * t.V * (ABSV ? 3 : 2) + (size_t)t.LDSX * 1024;
   if (t.V == 2)
     hipLaunchKernelGGL((vortdiv_rows_kernel<CHECK, WV, WD, ABSV, D, NT, 2>), dim3(grid), dim3(64 * t.WPB), lds, stream, rp);
   else if (t.V == 3)
