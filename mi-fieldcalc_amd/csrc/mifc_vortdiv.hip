@@ -72,6 +72,7 @@ struct RowsParams
   int nt_interior;     // 1: rows no other band touches are loaded nontemporally
   int exp_nohalo;      // MEASUREMENT ONLY (wrong results): halo rows are not fetched, to price their traffic
   int exp_nostore;     // MEASUREMENT ONLY: 1 = only lane-0-of-wave-0-like sliver of the stores is issued (read side alone)
+  int exp_noload;      // MEASUREMENT ONLY (wrong results): the field rows are not loaded at all (write side alone)
   long idx_lo, idx_hi; // valid flat element range relative to owned row 0 (for clamped scalar loads)
   const float *u, *v, *xm, *ym;
   const float* fc; // coriolis parameter, absvort only
@@ -219,6 +220,18 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
     const long base = (long)(jb + rowl) * nx;
     const bool stream_row = P.nt_interior && tc >= 1 && tc <= nr - 2;
     RowRegs<V> r;
+    if (P.exp_noload) { // write side alone: compute on something that costs no memory traffic
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const float f = (float)(tc + lane);
+        const v4f z = {f, f + 1.f, f * 2.f, f + 3.f};
+        r.u[q] = z;
+        r.v[q] = z;
+      }
+      r.eu = 0.f;
+      r.ev = 0.f;
+      return r;
+    }
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       if (stream_row) { // interior row of the band: read once by this wave only
@@ -669,6 +682,7 @@ struct Tuning
   int XH;    // measurement only: skip the halo rows (results are wrong), never set by the library itself
   int XS;    // measurement only: skip (practically all) stores
   int PADROWS; // measurement only: the last PADROWS rows of every level are padding (changes the level stride)
+  int XL;      // measurement only: skip the field loads (write side alone)
   int LDSX;    // extra KiB of LDS requested per workgroup: limits the workgroups resident on a CU (occupancy experiments)
 };
 
@@ -688,7 +702,7 @@ int tune_value(const char* s, const char* key, int dflt)
 
 Tuning current_tuning(int nx)
 {
-  Tuning t = {0, 8, 1, 1, 2, 1, 1, 8, 1, 0, 0, 0, 0, 0}; // R = 6 / WPB = 4 run within 1 % of this but fetch more (halo rows, map factors): HBM traffic 1.13-1.14x vs 1.08x of the minimum
+  Tuning t = {0, 8, 1, 1, 2, 1, 1, 8, 1, 0, 0, 0, 0, 0, 0}; // R = 6 / WPB = 4 run within 1 % of this but fetch more (halo rows, map factors): HBM traffic 1.13-1.14x vs 1.08x of the minimum
   // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,V=2,ORDER=1,XCD=1,WPB=8" -- used by the sweep tool and the tests
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     t.K = tune_value(s, "K", t.K);
@@ -708,6 +722,7 @@ Tuning current_tuning(int nx)
       t.XH = tune_value(s, "XH", 0);
       t.XS = tune_value(s, "XS", 0);
       t.PADROWS = tune_value(s, "PADROWS", 0);
+      t.XL = tune_value(s, "XL", 0);
     }
   }
   if (t.WPB != 1 && t.WPB != 2 && t.WPB != 4 && t.WPB != 8)
@@ -871,6 +886,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.nt_interior = t.NTI;
   rp.exp_nohalo = t.XH;
   rp.exp_nostore = t.XS;
+  rp.exp_noload = t.XL;
   rp.u = prm.f0;
   rp.v = prm.f1;
   rp.xm = prm.xmapr;
