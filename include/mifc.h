@@ -332,7 +332,9 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int 
  * stores, 2: nontemporal loads and stores.  blocks <= 0: one lane per 16 bytes;
  * otherwise a grid-stride loop over `blocks` workgroups of 256.  variant 3:
  * split-role copy (waves either load or store); variant 4: `blocks` workgroups
- * of 384 lanes, each streaming one contiguous chunk front to back.  Asynchronous. */
+ * of 384 lanes, each streaming one contiguous chunk front to back; variants 5-7:
+ * write-only (the sources are not read): linear, 4-row x 256-column tiles of
+ * 1440-column rows, waves looping over 8 rows of such a segment.  Asynchronous. */
 int mifc_bench_stream2(mifc_ctx* ctx, int variant, int blocks, float* dst0, float* dst1, const float* src0, const float* src1,
                        size_t n_floats);
 

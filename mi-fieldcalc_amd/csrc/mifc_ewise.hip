@@ -553,6 +553,42 @@ __global__ __launch_bounds__(384) void stream2_band_kernel(float* __restrict__ d
     __builtin_nontemporal_store(vb, y + q);
   }
 }
+// Variants 5-7: write-only yardsticks (the sources are not read).  5: one lane per 16 bytes of both
+// outputs, linear; 6: the same bytes as 1440-column rows written in tiles of ROWS x 256 columns per
+// 256-lane workgroup... (wave w of the workgroup writes row w of the tile), tiles in (row block,
+// column segment) order; 7: like 6 but every wave LOOPS over 8 rows of its 256-column segment.
+__global__ __launch_bounds__(256) void fill2_linear_kernel(float* __restrict__ d0, float* __restrict__ d1, size_t n4)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n4)
+    return;
+  const v4f c = {1.f, 2.f, 3.f, 4.f};
+  __builtin_nontemporal_store(c, reinterpret_cast<v4f*>(d0) + q);
+  __builtin_nontemporal_store(c, reinterpret_cast<v4f*>(d1) + q);
+}
+template <int ROWS_PER_WAVE>
+__global__ __launch_bounds__(256) void fill2_tiles_kernel(float* __restrict__ d0, float* __restrict__ d1, size_t nrows)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  constexpr int NX = 1440, SEG = 6; // 6 segments of 256 columns, the last one partly empty
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t rblock = blockIdx.x / SEG;
+  const int seg = (int)(blockIdx.x % SEG);
+  const int col = seg * 256 + lane * 4;
+  if (col >= NX)
+    return;
+  const v4f c = {1.f, 2.f, 3.f, 4.f};
+#pragma unroll 1
+  for (int k = 0; k < ROWS_PER_WAVE; ++k) {
+    const size_t row = (rblock * 4 + wave) * ROWS_PER_WAVE + k;
+    if (row >= nrows)
+      return;
+    const size_t o = row * NX + col;
+    __builtin_nontemporal_store(c, reinterpret_cast<v4f*>(d0 + o));
+    __builtin_nontemporal_store(c, reinterpret_cast<v4f*>(d1 + o));
+  }
+}
 } // namespace
 
 hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const float* s0, const float* s1, size_t n_floats, hipStream_t stream)
@@ -563,6 +599,20 @@ hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const f
     blocks = (int)(want > 0x7fffffff ? 0x7fffffff : want);
   }
   switch (variant) {
+  case 5:
+    hipLaunchKernelGGL(fill2_linear_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, d0, d1, n4);
+    break;
+  case 6:
+  case 7: {
+    const size_t nrows = n_floats / 1440;
+    const int rpw = variant == 6 ? 1 : 8;
+    const size_t rblocks = (nrows + 4 * rpw - 1) / (4 * rpw);
+    if (variant == 6)
+      hipLaunchKernelGGL(fill2_tiles_kernel<1>, dim3((unsigned)(rblocks * 6)), dim3(256), 0, stream, d0, d1, nrows);
+    else
+      hipLaunchKernelGGL(fill2_tiles_kernel<8>, dim3((unsigned)(rblocks * 6)), dim3(256), 0, stream, d0, d1, nrows);
+    break;
+  }
   case 4:
     hipLaunchKernelGGL(stream2_band_kernel, dim3(blocks), dim3(384), 0, stream, d0, d1, s0, s1, n4, (n4 + (size_t)blocks - 1) / (size_t)blocks);
     break;

@@ -38,6 +38,10 @@ YARD = {
     "band copy, 32-row chunks": (4, 3083),
     "band copy, 16-row chunks": (4, 6165),
     "band copy, 8-row chunks": (4, 12330),
+    # write-only yardsticks (half the bytes of the copies: the two outputs only)
+    "fill both outputs, linear one-shot": (5, 0),
+    "fill both outputs, 4x256-col tiles one-shot": (6, 0),
+    "fill both outputs, waves loop over 8 rows": (7, 0),
 }
 
 
