@@ -334,7 +334,8 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int 
  * split-role copy (waves either load or store); variant 4: `blocks` workgroups
  * of 384 lanes, each streaming one contiguous chunk front to back; variants 5-7:
  * write-only (the sources are not read): linear, 4-row x 256-column tiles of
- * 1440-column rows, waves looping over 8 rows of such a segment.  Asynchronous. */
+ * 1440-column rows, waves looping over 8 rows of such a segment; variant 8: 6-wave
+ * workgroups writing full rows, 8 rows each.  Asynchronous. */
 int mifc_bench_stream2(mifc_ctx* ctx, int variant, int blocks, float* dst0, float* dst1, const float* src0, const float* src1,
                        size_t n_floats);
 

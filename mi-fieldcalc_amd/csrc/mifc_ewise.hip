@@ -589,6 +589,27 @@ __global__ __launch_bounds__(256) void fill2_tiles_kernel(float* __restrict__ d0
     __builtin_nontemporal_store(c, reinterpret_cast<v4f*>(d1 + o));
   }
 }
+// Variant 8: write-only, a workgroup of 6 waves writes FULL 1440-column rows (wave w = the w-th 256-column
+// segment) and loops over 8 consecutive rows: what the operator's stores would look like if the waves of
+// a workgroup sat side by side on one level instead of on 8 different levels.
+__global__ __launch_bounds__(384) void fill2_fullrow_kernel(float* __restrict__ d0, float* __restrict__ d1, size_t nrows)
+{
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  constexpr int NX = 1440;
+  const int col = (int)threadIdx.x * 4;
+  if (col >= NX)
+    return;
+  const v4f c = {1.f, 2.f, 3.f, 4.f};
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    const size_t row = (size_t)blockIdx.x * 8 + k;
+    if (row >= nrows)
+      return;
+    const size_t o = row * NX + col;
+    __builtin_nontemporal_store(c, reinterpret_cast<v4f*>(d0 + o));
+    __builtin_nontemporal_store(c, reinterpret_cast<v4f*>(d1 + o));
+  }
+}
 } // namespace
 
 hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const float* s0, const float* s1, size_t n_floats, hipStream_t stream)
@@ -599,6 +620,11 @@ hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const f
     blocks = (int)(want > 0x7fffffff ? 0x7fffffff : want);
   }
   switch (variant) {
+  case 8: {
+    const size_t nrows = n_floats / 1440;
+    hipLaunchKernelGGL(fill2_fullrow_kernel, dim3((unsigned)((nrows + 7) / 8)), dim3(384), 0, stream, d0, d1, nrows);
+    break;
+  }
   case 5:
     hipLaunchKernelGGL(fill2_linear_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, d0, d1, n4);
     break;

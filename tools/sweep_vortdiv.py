@@ -42,6 +42,7 @@ YARD = {
     "fill both outputs, linear one-shot": (5, 0),
     "fill both outputs, 4x256-col tiles one-shot": (6, 0),
     "fill both outputs, waves loop over 8 rows": (7, 0),
+    "fill both outputs, 6-wave workgroups write full rows, 8 rows": (8, 0),
 }
 
 
