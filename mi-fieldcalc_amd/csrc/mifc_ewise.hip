@@ -44,7 +44,14 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
     r = absval(a, b);
     return true;
   }
-  case EW_TEMP: {
+  case EW_TEMP_SCALAR: { // pleveltemp compute 1..3, :347-356
+    if (!(all || is_def(a, undef)))
+      return false;
+    r = (P.compute == 1) ? (a * P.pidcp - MIFC_K_T0) : (P.compute == 2) ? (a * P.pidcp) : (a / P.pidcp);
+    return true;
+  }
+  case EW_TEMP:
+  case EW_TEMP_PLAIN: {
     float p, pidcp, pi;
     if (P.psrc == PS_SCALAR) { // pleveltemp :347-363 (p hoisted, evaluated on the host)
       if (!(all || is_def(a, undef)))
@@ -58,6 +65,10 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
       p = (P.psrc == PS_HYBRID) ? (P.alevel + P.blevel * c) : c; // :303
       pidcp = pidcp_of(PT, p);
       pi = pidcp * MIFC_K_CP;
+    }
+    if (OP == EW_TEMP_PLAIN) { // compute 1..3 only: no saturation table in this instantiation
+      r = (P.compute == 1) ? (a * pidcp - MIFC_K_T0) : (P.compute == 2) ? (a * pidcp) : (a / pidcp);
+      return true;
     }
     switch (P.compute) {
     case 1:
@@ -78,7 +89,8 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
       return true;
     }
   }
-  case EW_HUM: {
+  case EW_HUM:
+  case EW_HUM_DIRECT: {
     bool ok = all || (is_def(a, undef) && is_def(b, undef)); // :443, :1187, :1429
     if (P.ptest == PT_NEQ)
       ok = ok && (all || c != undef);
@@ -95,6 +107,8 @@ __device__ __forceinline__ bool ewise_point(const EwiseParams& P, const float* t
         p = c;
       tk = P.from_theta ? a * pidcp_of(PT, p) : a;
     }
+    if (OP == EW_HUM_DIRECT) // q <-> RH: no table inverse in this instantiation
+      return (P.kind == HUM_Q_RH) ? tk_q_rh(tab, tk, b, p, r) : tk_rh_q(tab, tk, b, p, r);
     switch (P.kind) {
     case HUM_Q_RH:
       return tk_q_rh(tab, tk, b, p, r);
@@ -160,17 +174,18 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
   __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
   // the lookup tables cost a few hundred cycles per workgroup: staged only
   // for the operator variants that read them (wave-uniform conditions)
-  if (ewise_needs_ewt(P))
+  constexpr bool TABLE_FREE = (OP == EW_TEMP_SCALAR || OP == EW_VECTORABS || OP == EW_MOMENTUM_X || OP == EW_MOMENTUM_Y);
+  if (!TABLE_FREE && ewise_needs_ewt(P))
     ewt_table_init(s_ewt);
   PowTables PT;
   PT.logt = s_pow;
   PT.expt = s_pow + 2 * MIFC_POW_LOG_N;
-  if (ewise_needs_pow(P))
+  if (!TABLE_FREE && ewise_needs_pow(P))
     PT = pow_tables_init(s_pow);
 
   const bool use1 = P.in1 != nullptr;
   const bool use2 = P.in2 != nullptr;
-  const bool may_keep = (OP == EW_TEMP) && (P.compute < 1 || P.compute > 5);
+  const bool may_keep = (OP == EW_TEMP) && (P.compute < 1 || P.compute > 5); // the _SCALAR / _PLAIN instantiations only see compute 1..3
   unsigned int bad = 0;
 
   if (VEC4) {
@@ -284,8 +299,12 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
   case EW_VECTORABS:
     return launch_ewise_op<EW_VECTORABS>(prm, stream);
   case EW_TEMP:
+    if (prm.compute >= 1 && prm.compute <= 3)
+      return prm.psrc == PS_SCALAR ? launch_ewise_op<EW_TEMP_SCALAR>(prm, stream) : launch_ewise_op<EW_TEMP_PLAIN>(prm, stream);
     return launch_ewise_op<EW_TEMP>(prm, stream);
   case EW_HUM:
+    if (prm.kind == HUM_Q_RH || prm.kind == HUM_RH_Q)
+      return launch_ewise_op<EW_HUM_DIRECT>(prm, stream);
     return launch_ewise_op<EW_HUM>(prm, stream);
   case EW_CVHUM_TD:
     return launch_ewise_op<EW_CVHUM_TD>(prm, stream);

@@ -17,7 +17,14 @@ enum EwiseOp {
   EW_CVHUM_TD = 3,  // cvhum compute 1..3 :1759-1785
   EW_CVHUM_RH = 4,  // cvhum compute 4,5 :1787-1811
   EW_MOMENTUM_X = 5, // momentumXcoordinate :2351: in0 = v, in1 = xmapr, in2 = fcoriolis
-  EW_MOMENTUM_Y = 6  // momentumYcoordinate :2387: in0 = u, in1 = ymapr, in2 = fcoriolis
+  EW_MOMENTUM_Y = 6, // momentumYcoordinate :2387: in0 = u, in1 = ymapr, in2 = fcoriolis
+  // kernel-internal: EW_TEMP with a scalar pressure and compute 1..3 (pleveltemp's plain conversions) as a
+  // small kernel of its own; launch_ewise() selects it, callers keep passing EW_TEMP
+  EW_TEMP_SCALAR = 7,
+  // likewise: EW_TEMP with a hybrid / field pressure and compute 1..3 (no saturation table in the kernel),
+  // EW_HUM for the two kinds that need no table inverse (q <-> RH)
+  EW_TEMP_PLAIN = 8,
+  EW_HUM_DIRECT = 9
 };
 enum PressureSource { PS_SCALAR = 0, PS_HYBRID = 1, PS_FIELD = 2 };
 enum HumKind { HUM_Q_RH = 0, HUM_RH_Q = 1, HUM_Q_TD = 2, HUM_RH_TD = 3 };
