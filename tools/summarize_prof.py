@@ -11,7 +11,14 @@ from collections import defaultdict
 
 
 def find(root, pattern):
-    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+    # gpurun merges the output of successive runs into the same local directories: per directory, only
+    # the newest file counts (on the GPU box itself there is only one)
+    newest = {}
+    for f in glob.glob(os.path.join(root, "**", pattern), recursive=True):
+        d = os.path.dirname(f)
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+            newest[d] = f
+    return sorted(newest.values())
 
 
 def main():
@@ -25,6 +32,17 @@ def main():
             name = r.get("Name", "")[:90]
             print("  %-90s calls=%s avg_ns=%s min_ns=%s max_ns=%s pct=%s" % (
                 name, r.get("Calls"), r.get("AverageNs"), r.get("MinNs"), r.get("MaxNs"), r.get("Percentage")))
+    # ---- what bench.py itself measured (HIP events) inside the traced process, for comparison
+    tlog = os.path.join(root, "trace.log")
+    if os.path.exists(tlog):
+        for line in open(tlog):
+            if line.startswith("{") and '"roofline"' in line:
+                try:
+                    d = json.loads(line)
+                    print("== bench.py inside the traced process: %.1f Mcells/s, kernel %.4f ms avg / %.4f ms min by HIP events over %d timed steps"
+                          % (d["value"], d["roofline"]["kernel_ms_avg"], d["roofline"]["kernel_ms_min"], d["steps"]))
+                except (ValueError, KeyError):
+                    pass
     # ---- counters: average per dispatch of the headline kernel
     per_counter = defaultdict(list)
     regs = {}
