@@ -5,6 +5,7 @@
 #include "mifc_ctx.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 using namespace mifc_host;
@@ -586,7 +587,25 @@ int mifc_shapiro2_filter(mifc_ctx* c, int nx, int ny, const float* field, float*
   const float* d_in = stage_in(c, 0, field, n, memkind, &ok);
   float* d_out = stage_out(c, 5, fsmooth, n, memkind, &ok);
   const bool all = (*fdefined == MIFC_ALL_DEFINED);
-  if (!ok || !ensure_slot(c, 8, n * sizeof(float)) || (!all && !ensure_slot(c, 9, 2 * n)))
+  if (!ok || !ensure_slot(c, 8, n * sizeof(float)))
+    return 0;
+  {
+    // the four sweeps in one launch; it needs source and destination to be different arrays, so an
+    // in-place call goes through the scratch field and is copied back
+    const char* e = std::getenv("MIFC_SHAPIRO_FUSED"); // "0": the four-launch path (A/B measurements, tests)
+    float* d_dst = (d_out != d_in) ? d_out : static_cast<float*>(c->slot[8]);
+    if (!(e && e[0] == '0') && mifc::shapiro2_fused_supported(nx, ny, d_in, d_dst)) {
+      MIFC_LAUNCH(c, mifc::launch_shapiro2_fused(nx, ny, all ? 1 : 0, undef, d_in, d_dst, c->stream));
+      if (d_dst != d_out)
+        MIFC_HIP(c, hipMemcpyAsync(d_out, d_dst, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      if (!fetch_out(c, 5, fsmooth, n, memkind))
+        return 0;
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+      *fdefined = MIFC_ALL_DEFINED;
+      return 1;
+    }
+  }
+  if (!all && !ensure_slot(c, 9, 2 * n))
     return 0;
   if (d_out != d_in)
     MIFC_HIP(c, hipMemcpyAsync(d_out, d_in, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));

@@ -82,6 +82,13 @@ __device__ __forceinline__ float from_upper_lane(float keep_if_none, float x)
   return __builtin_bit_cast(float,
                             __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
 }
+// A row written to LDS is read back by OTHER lanes of the wave (x-neighbours).  The hardware keeps a
+// wave's LDS operations in order; this keeps the compiler from moving a neighbour's read above the write
+// (for one lane the two addresses never overlap, so it would be free to).
+__device__ __forceinline__ void lds_rows_visible()
+{
+  asm volatile("" ::: "memory");
+}
 // {west, own four, east} of a ring row
 __device__ __forceinline__ void row6(const float* row, int p, float (&v)[6])
 {
@@ -344,6 +351,8 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
       }
     }
 
+    lds_rows_visible();
+
     // ---- stage B: result row j = r-2, owned groups
     const int j = r - 2;
     const bool have_row = owned && j >= jb0 && j < jb1;
@@ -420,6 +429,7 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
       if (load_a)
         *reinterpret_cast<float4*>(ringA + ((r + 1) % RA) * TS + p) = pa;
     }
+    lds_rows_visible();
     if (!TFP)
       t_south = m_b.t; // row r-2 is row (r+1)-3
     if (have_row) {

@@ -240,6 +240,9 @@ struct ShapiroParams
   unsigned char* mask_y;
 };
 hipError_t launch_shapiro2(const ShapiroParams& prm, hipStream_t stream);
+// The four sweeps in one launch, src -> dst (two different arrays); nx % 4 == 0, 16-byte aligned.
+bool shapiro2_fused_supported(int nx, int ny, const float* src, const float* dst);
+hipError_t launch_shapiro2_fused(int nx, int ny, int all_defined, float undef, const float* src, float* dst, hipStream_t stream);
 
 // Stencil-of-a-stencil operators in one launch (mifc_fused2.hip): the
 // intermediate field(s) of thermalFrontParameter (:2266) and plevelqvector

@@ -57,6 +57,210 @@ __global__ __launch_bounds__(256) void shapiro_sweep_kernel(const float* __restr
 
 } // namespace
 
+// ---------------------------------------------------------------------------
+// The four sweeps in ONE launch, built like mifc_fused2.hip: one wave per workgroup owns a tile of 240
+// columns (60 float4 column groups + one halo group on either side) and walks down a band of rows; the
+// rows it still needs live in LDS rings of 1-KiB rows, and since nothing is shared between waves there
+// is no barrier.  Per iteration r (F = the unsmoothed field, A/B/C/D = after sweep 1/2/3/4):
+//   A(r)   from F(r) and its x-neighbours              -> ring A
+//   B(r-1) from A(r-2), A(r-1), A(r)                   -> one LDS row (its x-neighbours are needed next)
+//   C(r-1) from B(r-1) and its x-neighbours            -> ring C
+//   D(r-2) from C(r-3), C(r-2), C(r-1)                 -> stored
+// The per-cell weights of the tested variant come from the UNSMOOTHED field (:2141-2145), so F rows
+// r-3..r stay in their ring.  The x sweeps keep columns 0 / nx-1, the y sweeps rows 0 / ny-1.
+// Reads src, writes dst: the two must be different arrays (halo rows and columns are read by
+// neighbouring waves after their owner may have been written).
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int S2_TW = 240, S2_TS = S2_TW + 16, S2_TQ = S2_TW / 4 + 2;
+
+// A row written to LDS is read back by OTHER lanes of the wave (x-neighbours).  The hardware keeps a
+// wave's LDS operations in order; this keeps the compiler from moving a neighbour's read above the write
+// (for one lane the two addresses never overlap, so it would be free to).
+__device__ __forceinline__ void lds_rows_visible()
+{
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ float4 s2_ld4(const float* p)
+{
+  return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void s2_unpack(const float4 q, float (&v)[4])
+{
+  v[0] = q.x;
+  v[1] = q.y;
+  v[2] = q.z;
+  v[3] = q.w;
+}
+__device__ __forceinline__ void s2_row6(const float* row, int p, float (&v)[6])
+{
+  const float4 q = s2_ld4(row + p);
+  v[0] = row[p - 1];
+  v[1] = q.x;
+  v[2] = q.y;
+  v[3] = q.z;
+  v[4] = q.w;
+  v[5] = row[p + 4];
+}
+// one cell of a sweep: centre c, the two neighbours a and b along the sweep direction
+template <bool ALL>
+__device__ __forceinline__ float s2_update(float c, float a, float b, float s, bool weighted)
+{
+  if (ALL) // :2115, :2123
+    return (float)((double)c + (double)s * ((double)(a + b) - 2. * (double)c));
+  return c + (weighted ? 0.25f : 0.f) * (a + b - 2 * c); // :2152, :2160
+}
+
+template <bool ALL>
+__global__ __launch_bounds__(64) void shapiro2_tile_kernel(const float* __restrict__ src, float* __restrict__ dst, const int nx, const int ny,
+                                                           const float undef, const int band, const int ntiles)
+{
+  constexpr int RF = 5; // F rows r-3..r are live in an iteration, row r+1 lands at its end
+  __shared__ float4 lds4[(RF + 3 + 1 + 3) * S2_TS / 4];
+  float* ringF = reinterpret_cast<float*>(lds4);
+  float* ringA = ringF + RF * S2_TS;
+  float* rowB = ringA + 3 * S2_TS;
+  float* ringC = rowB + S2_TS;
+
+  const int lane = threadIdx.x;
+  const int tile = (int)blockIdx.x % ntiles;
+  const int bidx = (int)blockIdx.x / ntiles;
+  const int xq = tile * S2_TW - 4 + 4 * lane;
+  const bool loadable = lane < S2_TQ && xq >= 0 && xq < nx;
+  const bool owned = loadable && lane >= 1 && lane <= S2_TW / 4;
+  const int p = 4 + 4 * lane;
+  const bool first_col = xq == 0, last_col = xq + 4 == nx; // the group holds column 0 / nx-1: the x sweeps keep them
+
+  const int jb0 = bidx * band; // output rows [jb0, jb1)
+  const int jb1 = (jb0 + band < ny) ? jb0 + band : ny;
+  const int rs = jb0 - 2, re = jb1 + 1;
+  const size_t ccol = (size_t)(loadable ? xq : tile * S2_TW);
+  auto clamp_row = [&](int r) { return (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + ccol; };
+  auto slot = [](int r, int n) { return ((r % n) + n) % n; }; // r may be negative near the top of the field
+  if (loadable && rs >= 0)
+    *reinterpret_cast<float4*>(ringF + slot(rs, RF) * S2_TS + p) = s2_ld4(src + clamp_row(rs));
+
+  // is_def of the three cells of a stencil in the unsmoothed field
+  auto def3 = [&](float a, float c, float b) { return is_def(a, undef) && is_def(c, undef) && is_def(b, undef); };
+
+#pragma unroll 1
+  for (int r = rs; r <= re; ++r) {
+    const bool land = r < re && r + 1 >= 0 && r + 1 < ny;
+    const float4 pf = s2_ld4(src + clamp_row(r + 1)); // lands in ring F at the end of the iteration
+
+    // ---- sweep 1 (x, weight s = 0.25): A(r)
+    if (loadable && r >= 0 && r < ny) {
+      float f[6], a[4];
+      s2_row6(ringF + slot(r, RF) * S2_TS, p, f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        a[k] = s2_update<ALL>(f[k + 1], f[k], f[k + 2], 0.25f, ALL || def3(f[k], f[k + 1], f[k + 2]));
+      if (first_col)
+        a[0] = f[1];
+      if (last_col)
+        a[3] = f[4];
+      *reinterpret_cast<float4*>(ringA + slot(r, 3) * S2_TS + p) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+    // ---- sweep 2 (y): B(r-1), then sweep 3 (x, weight -0.25 / the same per-cell weights again): C(r-1)
+    const int y = r - 1;
+    if (loadable && y >= 0 && y < ny && y >= jb0 - 1 && y <= jb1) {
+      float ac[4], b[4];
+      s2_unpack(s2_ld4(ringA + slot(y, 3) * S2_TS + p), ac);
+      if (y >= 1 && y <= ny - 2) {
+        float as[4], an[4], fs[4], fc[4], fn[4];
+        s2_unpack(s2_ld4(ringA + slot(y - 1, 3) * S2_TS + p), as);
+        s2_unpack(s2_ld4(ringA + slot(y + 1, 3) * S2_TS + p), an);
+        if (!ALL) {
+          s2_unpack(s2_ld4(ringF + slot(y - 1, RF) * S2_TS + p), fs);
+          s2_unpack(s2_ld4(ringF + slot(y, RF) * S2_TS + p), fc);
+          s2_unpack(s2_ld4(ringF + slot(y + 1, RF) * S2_TS + p), fn);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          b[k] = s2_update<ALL>(ac[k], as[k], an[k], 0.25f, ALL || def3(fs[k], fc[k], fn[k]));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          b[k] = ac[k]; // rows 0 and ny-1 pass through (:2125-2128)
+      }
+      lds_rows_visible(); // the neighbours' reads of the previous B row are issued
+      *reinterpret_cast<float4*>(rowB + p) = make_float4(b[0], b[1], b[2], b[3]);
+      lds_rows_visible();
+      float bb[6], f[6], c[4];
+      s2_row6(rowB, p, bb);
+      if (!ALL)
+        s2_row6(ringF + slot(y, RF) * S2_TS, p, f);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        c[k] = s2_update<ALL>(bb[k + 1], bb[k], bb[k + 2], -0.25f, ALL || def3(f[k], f[k + 1], f[k + 2]));
+      if (first_col)
+        c[0] = bb[1];
+      if (last_col)
+        c[3] = bb[4];
+      *reinterpret_cast<float4*>(ringC + slot(y, 3) * S2_TS + p) = make_float4(c[0], c[1], c[2], c[3]);
+    }
+    // ---- sweep 4 (y): D(r-2), owned groups of owned rows
+    const int j = r - 2;
+    const bool have_row = owned && j >= jb0 && j < jb1;
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    if (have_row) {
+      float cc[4];
+      s2_unpack(s2_ld4(ringC + slot(j, 3) * S2_TS + p), cc);
+      if (j >= 1 && j <= ny - 2) {
+        float cs[4], cn[4], fs[4], fc[4], fn[4];
+        s2_unpack(s2_ld4(ringC + slot(j - 1, 3) * S2_TS + p), cs);
+        s2_unpack(s2_ld4(ringC + slot(j + 1, 3) * S2_TS + p), cn);
+        if (!ALL) {
+          s2_unpack(s2_ld4(ringF + slot(j - 1, RF) * S2_TS + p), fs);
+          s2_unpack(s2_ld4(ringF + slot(j, RF) * S2_TS + p), fc);
+          s2_unpack(s2_ld4(ringF + slot(j + 1, RF) * S2_TS + p), fn);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          d[k] = s2_update<ALL>(cc[k], cs[k], cn[k], -0.25f, ALL || def3(fs[k], fc[k], fn[k]));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          d[k] = cc[k];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the loaded row; the previous store is an iteration old
+    if (loadable && land)
+      *reinterpret_cast<float4*>(ringF + slot(r + 1, RF) * S2_TS + p) = pf;
+    lds_rows_visible();
+    if (have_row) {
+      const v4f q = {d[0], d[1], d[2], d[3]};
+      __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(dst + (size_t)j * nx + xq));
+    }
+  }
+}
+
+} // namespace
+
+bool shapiro2_fused_supported(int nx, int ny, const float* src, const float* dst)
+{
+  return nx >= 4 && (nx & 3) == 0 && ny >= 3 && src != dst && (reinterpret_cast<size_t>(src) & 15u) == 0 && (reinterpret_cast<size_t>(dst) & 15u) == 0;
+}
+
+hipError_t launch_shapiro2_fused(int nx, int ny, int all_defined, float undef, const float* src, float* dst, hipStream_t stream)
+{
+  const int ntiles = (nx + S2_TW - 1) / S2_TW;
+  const long want_bands = (256L * 12 * 4 + ntiles - 1) / ntiles;
+  int band = (int)((ny + want_bands - 1) / want_bands);
+  if (band < 4)
+    band = 4;
+  if (band > 64)
+    band = 64;
+  const int nbands = (ny + band - 1) / band;
+  if (all_defined)
+    hipLaunchKernelGGL((shapiro2_tile_kernel<true>), dim3((unsigned)(nbands * ntiles)), dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles);
+  else
+    hipLaunchKernelGGL((shapiro2_tile_kernel<false>), dim3((unsigned)(nbands * ntiles)), dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles);
+  return hipGetLastError();
+}
+
 hipError_t launch_shapiro2(const ShapiroParams& P, hipStream_t stream)
 {
   const int n = P.nx * P.ny;

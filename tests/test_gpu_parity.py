@@ -70,6 +70,20 @@ def test_scalar_row_kernels_band_heights(gpu_ctx, oracle, rows, monkeypatch):
             _check_case(gpu_ctx, oracle, case, device=True)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_shapiro_filter_one_launch_and_four(gpu_ctx, oracle, fused, monkeypatch):
+    """The four sweeps in one launch (tiles of 240 columns, bands of rows) == the sweep-by-sweep path == the reference."""
+    import mi_fieldcalc_amd.synth as synth
+
+    monkeypatch.setenv("MIFC_SHAPIRO_FUSED", fused)
+    for nx, ny in [(4, 3), (8, 5), (236, 7), (240, 9), (244, 12), (484, 5), (128, 301), (1440, 37), (5000, 4)]:
+        z = synth.scalar_field(nx, ny, 3 * nx + ny)
+        for mode in cases.MODES:
+            (z_,), flag = cases._apply_mode([z], mode, nx + ny, cases._frac(nx, ny))
+            case = dict(nx=nx, ny=ny, fdefined=flag, undef=cases.UNDEF, op="shapiro2_filter", args=[z_], label="shapiro2-%dx%d-%s" % (nx, ny, mode))
+            _check_case(gpu_ctx, oracle, case, device=(nx % 8 == 0))
+
+
 def test_elementwise_host_pointers(gpu_ctx, oracle):
     for case in cases.ewise_cases():
         _check_case(gpu_ctx, oracle, case, device=False)
@@ -119,14 +133,15 @@ def test_python_surface_matches_reference_module(gpu_ctx, oracle):
         pyfc.vesselIcingMincog(*([t] * 11), 5.0, 0.5, 1.0, 4.0, 1, 1e35)
 
 
+@pytest.mark.parametrize("nx,ny", [(129, 40), (128, 40), (484, 71), (1440, 9)])
 @pytest.mark.parametrize("flag", [ALL, SOME])
-def test_shapiro_filter_in_place(gpu_ctx, oracle, flag):
-    """shapiro2_filter allows field == fsmooth (FieldCalculations.cc:2088, :2099): device tensor smoothed in place."""
+def test_shapiro_filter_in_place(gpu_ctx, oracle, flag, nx, ny):
+    """shapiro2_filter allows field == fsmooth (FieldCalculations.cc:2088, :2099): device tensor smoothed in place
+    (widths the one-launch kernel takes, and one it does not)."""
     import torch
 
     import mi_fieldcalc_amd.synth as synth
 
-    nx, ny = 129, 40
     z = synth.scalar_field(nx, ny, 77)
     if flag == SOME:
         z = synth.sprinkle_undef(z, 5, 0.05)

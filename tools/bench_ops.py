@@ -141,6 +141,7 @@ def main():
     add("jacobian (one tall field)", 20, 0, lambda: ctx.jacobian(tall(z), tall(u), xm_t, ym_t, fdefined=ALLD, out=o_t), "jacobian", [h["z"], h["u"], xm, ym])
     add("jacobian (level batch)", 12, 2 * 4 * n, lambda: ctx.stencil_levels("jacobian", z, u, dxm, dym, fdefined=flags, out0=out), "jacobian",
         [h["z"], h["u"], xm, ym])
+    add("shapiro2_filter", 8, 0, lambda: ctx.shapiro2_filter(tall(z), fdefined=ALLD, out=o_t), "shapiro2_filter", [h["z"]])
     add("thermalFrontParameter", 16, 0, lambda: ctx.thermalFrontParameter(tall(t), xm_t, ym_t, fdefined=ALLD, out=o_t),
         "thermalFrontParameter", [h["t"], xm, ym])
     add("plevelqvector c=1", 24, 0, lambda: ctx.plevelqvector(tall(z), tall(t), xm_t, ym_t, fc_t, 500.0, 1, fdefined=ALLD, out=o_t),
