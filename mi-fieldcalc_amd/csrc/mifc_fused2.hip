@@ -351,7 +351,9 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
       }
     }
 
-    lds_rows_visible();
+    // (no compiler barrier needed here: stage B takes x-neighbours only from intermediate row r-2, written an
+    // iteration ago -- the barrier at the end of every iteration lies in between -- and from row r-1 only
+    // the lane's own column group)
 
     // ---- stage B: result row j = r-2, owned groups
     const int j = r - 2;
