@@ -707,3 +707,42 @@ def test_fused_tfp_and_qvector_random_shapes(gpu_ctx, oracle):
         c = 1 + k % 4
         _check_case(gpu_ctx, oracle, dict(base, op="plevelqvector", args=[z_, tq, xm, ym, fc, 850.0, c], label="qvector%d-%s" % (c, lab)),
                     device=bool(k & 1))
+
+
+@pytest.mark.parametrize("mode", ["all", "some"])
+def test_one_launch_kernels_equal_their_multi_pass_paths_on_a_large_field(gpu_ctx, mode, monkeypatch):
+    """1440 x 11520 (16 levels seen as one tall field, far beyond what the CPU oracle checks in seconds): the
+    one-launch forms of thermalFrontParameter, plevelqvector and shapiro2_filter give bit for bit what the
+    pass-by-pass kernels give (which the seeded cases pin to the reference), flags included."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 1440, 720, 16
+    xm, ym, fcor = synth.grid_maps(nx, ny)
+    tall = lambda a: torch.from_numpy(np.ascontiguousarray(np.tile(a, (nlev, 1)))).cuda()
+    dxm, dym, dfc = tall(xm), tall(ym), tall(fcor)
+    z = np.concatenate([synth.scalar_field(nx, ny, 900 + l) for l in range(nlev)], axis=0)
+    flag = ALL
+    if mode == "some":
+        z = synth.sprinkle_undef(z, 17, 0.001)
+        z[5000:5003, 700:720] = np.float32(5432.0)  # a small plateau: |grad| == 0
+        flag = SOME
+    dz = torch.from_numpy(z).cuda()
+    dt = torch.where((dz == float(cases.UNDEF)) | torch.isnan(dz), dz, 250.0 + 0.05 * (dz - 5500.0)).contiguous()
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = {}
+        out["tfp"] = gpu_ctx.thermalFrontParameter(dz, dxm, dym, fdefined=flag)
+        for c in (1, 4):
+            out["q%d" % c] = gpu_ctx.plevelqvector(dz, dt, dxm, dym, dfc, 700.0, c, fdefined=flag)
+        out["shapiro"] = gpu_ctx.shapiro2_filter(dz, fdefined=flag)
+        return {k: (v[0].cpu().numpy(), v[1]) for k, v in out.items()}
+
+    one = run({"MIFC_FUSED2": "1", "MIFC_SHAPIRO_FUSED": "1"})
+    many = run({"MIFC_FUSED2": "0", "MIFC_SHAPIRO_FUSED": "0"})
+    for k in one:
+        assert one[k][1] == many[k][1], (k, one[k][1], many[k][1])
+        assert cases.same_bits(one[k][0], many[k][0], nan_payload=False), k
