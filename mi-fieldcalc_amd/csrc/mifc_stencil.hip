@@ -16,6 +16,8 @@
 //                         ragged widths, row slabs and the less common operators.
 //   (the row-walking kernels that take over whenever nx % 4 == 0 are in
 //    mifc_vortdiv.hip -- wind operators -- and mifc_stencil_rows.hip)
+#include <cstdlib>
+
 #include "mifc_device.h"
 #include "mifc_kernels.h"
 
@@ -259,6 +261,7 @@ hipError_t launch_cell(const StencilParams& prm, hipStream_t stream)
 
 hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, bool* handled); // mifc_vortdiv.hip
 hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool* handled);  // mifc_stencil_rows.hip
+hipError_t launch_advection_oneshot(const StencilParams& prm, hipStream_t stream, bool* handled); // mifc_advection.hip
 
 hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
 {
@@ -273,6 +276,12 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
   if (prm.op >= ST_GRAD_X && prm.op <= ST_IGWIND) {
     bool handled = false;
     const hipError_t e = launch_scalar_rows(prm, stream, &handled);
+    if (handled)
+      return e;
+  }
+  if (prm.op == ST_ADVECTION && !std::getenv("MIFC_FORCE_CELL_KERNEL")) {
+    bool handled = false;
+    const hipError_t e = launch_advection_oneshot(prm, stream, &handled);
     if (handled)
       return e;
   }
