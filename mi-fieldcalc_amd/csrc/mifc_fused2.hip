@@ -178,8 +178,7 @@ __device__ __attribute__((noinline)) float absdelt_filled_at(const Fused2Params&
 }
 
 // The cells of columns 0 and nx-1, rows 1..ny-2: only their contribution to the counts (their values
-// are fill copies).  Run by a few extra workgroups at the end of the grid (Q-vector) or a small launch
-// of their own (TFP with a tested input); lane = (row, side); everything comes from global memory, with the neighbours the
+// are fill copies).  Run by a few extra workgroups at the end of the grid; lane = (row, side); everything comes from global memory, with the neighbours the
 // flat loop of the reference sees: west of column 0 is (nx-1, j-1), east of column nx-1 is (0, j+1).
 template <int OP, bool CHECK>
 __device__ __forceinline__ void edge_count_cells(const Fused2Params& P, const int first, const int stride)
@@ -242,7 +241,7 @@ template <int OP, bool CHECK>
 __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_tile_kernel(const Fused2Params P, const int band, const int ntiles, const int n_main)
 {
   constexpr bool TFP = OP == F2_TFP;
-  if (!TFP && (int)blockIdx.x >= n_main) { // Q-vector: the workgroups behind the tiles count the edge-column cells
+  if ((!TFP || CHECK) && (int)blockIdx.x >= n_main) { // the workgroups behind the tiles count the edge-column cells
     edge_count_cells<OP, CHECK>(P, ((int)blockIdx.x - n_main) * 64 + (int)threadIdx.x, ((int)gridDim.x - n_main) * 64);
     return;
   }
@@ -474,14 +473,6 @@ bool aligned16(const void* p)
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
-// TFP with a tested input: its edge cells as a launch of their own (inlined behind the tiles like the
-// Q-vector's, the two code paths together spill registers)
-template <int OP, bool CHECK>
-__global__ __launch_bounds__(256) void fused2_edge_count_kernel(const Fused2Params P)
-{
-  edge_count_cells<OP, CHECK>(P, (int)(blockIdx.x * 256 + threadIdx.x), (int)gridDim.x * 256);
-}
-
 template <int OP, bool CHECK>
 hipError_t launch(const Fused2Params& p, hipStream_t stream)
 {
@@ -506,13 +497,7 @@ hipError_t launch(const Fused2Params& p, hipStream_t stream)
     if (n_edge > 256)
       n_edge = 256;
   }
-  if (OP == F2_TFP) {
-    hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)n_main), dim3(64), 0, stream, p, band, ntiles, n_main);
-    if (n_edge > 0)
-      hipLaunchKernelGGL((fused2_edge_count_kernel<OP, CHECK>), dim3((unsigned)((n_edge + 3) / 4)), dim3(256), 0, stream, p);
-  } else {
-    hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(n_main + n_edge)), dim3(64), 0, stream, p, band, ntiles, n_main);
-  }
+  hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(n_main + n_edge)), dim3(64), 0, stream, p, band, ntiles, n_main);
   return hipGetLastError();
 }
 
