@@ -300,9 +300,107 @@ level_done:
     wave_count_add(P.n_undefined + lev, bad);
 }
 
+// One-shot form for small launches (the reference's single-field call): no row loop, no LDS -- a workgroup
+// is 4 waves = 4 rows x 256 columns of one level; every lane loads the float4 of its own row and of the
+// rows above and below plus the map factors it needs, takes its x-neighbours from the adjacent lanes and
+// stores.  A wave lives for one memory round trip; with fewer than ~2000 waves in the launch that beats
+// walking even 2-row bands.
+template <int OP, bool CHECK>
+__global__ __launch_bounds__(256) void scalar_oneshot_kernel(const SRowsParams P)
+{
+  constexpr bool USE_XM = (OP != ST_GRAD_Y && OP != ST_GWIND_X);
+  constexpr bool USE_YM = (OP != ST_GRAD_X && OP != ST_GWIND_Y);
+  constexpr bool USE_FC = (OP == ST_GWIND_X || OP == ST_GWIND_Y || OP == ST_GVORT || OP == ST_IGWIND);
+  constexpr bool TWO_OUT = (OP == ST_IGWIND);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int seq = blockIdx.x; // address order: column segment fastest, then row block, then level
+  const int per_level = P.uB * P.uW;
+  const int lev = seq / per_level;
+  const int rem = seq - lev * per_level;
+  const int rblock = rem / P.uW;
+  const int wc = rem - rblock * P.uW;
+  const int nx = P.nx, ny = P.ny;
+  const int j = 1 + rblock * 4 + wave;
+  if (j > ny - 2)
+    return;
+  const int col = wc * 256 + lane * 4;
+  const bool act = col < nx;
+  const int col_c = act ? col : nx - 4;
+  int east_col = wc * 256 + 256;
+  if (east_col > nx)
+    east_col = nx;
+  const int edge_col = (lane == 63) ? east_col : (wc * 256 - 1);
+  const float undef = P.undef;
+  const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
+  const float* __restrict__ f = P.f + (size_t)lev * P.in_stride;
+  const long base = (long)j * nx;
+  const long o = base + col_c;
+  const v4f fc = ld4(f + o), fn = ld4(f + o + nx), fs = ld4(f + o - nx);
+  v4f xm4 = fc, ym4 = fc, co4 = fc;
+  if (USE_XM)
+    xm4 = ld4(P.xm + o);
+  if (USE_YM)
+    ym4 = ld4(P.ym + o);
+  if (USE_FC)
+    co4 = ld4(P.fc + o);
+  const float ef = f[base + edge_col]; // (nx-1, j-1) west of column 0, (0, j+1) east of column nx-1: the flat loop's neighbours
+
+  const float east = lane_value(ef, 63);
+  const float fW = dpp_lower(ef, fc.w);
+  float fE = dpp_upper(ef, fc.x);
+  if (col + 4 >= east_col)
+    fE = east;
+  const float fc6[6] = {fW, fc.x, fc.y, fc.z, fc.w, fE};
+  float z0[4], z1[4];
+  unsigned int bad = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float r0 = undef, r1 = undef;
+    const bool ok = scalar_cell<OP, CHECK>(all, undef, fc6[k], fc6[k + 1], fc6[k + 2], fs[k], fn[k], xm4[k], ym4[k], co4[k], r0, r1);
+    z0[k] = ok ? r0 : undef;
+    z1[k] = ok ? r1 : undef;
+    if (CHECK && !ok && act)
+      bad += 1;
+  }
+  if (col == 0) { // fillEdges, column part
+    z0[0] = z0[1];
+    z1[0] = z1[1];
+  }
+  if (col + 4 == nx) {
+    z0[3] = z0[2];
+    z1[3] = z1[2];
+  }
+  if (act) {
+    float* o0p = P.o0 + (size_t)lev * P.out_stride;
+    const long oo = base + col;
+    st4_stream(o0p + oo, z0);
+    if (j == 1) // fillEdges, row part
+      st4_stream(o0p + oo - nx, z0);
+    if (j == ny - 2)
+      st4_stream(o0p + oo + nx, z0);
+    if (TWO_OUT) {
+      float* o1p = P.o1 + (size_t)lev * P.out_stride;
+      st4_stream(o1p + oo, z1);
+      if (j == 1)
+        st4_stream(o1p + oo - nx, z1);
+      if (j == ny - 2)
+        st4_stream(o1p + oo + nx, z1);
+    }
+  }
+  if (CHECK && P.n_undefined)
+    wave_count_add(P.n_undefined + lev, bad);
+}
+
 template <int OP>
 void launch_op(const SRowsParams& rp, bool check, int V, int grid, size_t lds, hipStream_t stream)
 {
+  if (V == 0) { // one-shot form: rp.uB / rp.uW are row blocks of 4 / 256-column segments, grid = levels * uB * uW
+    if (check)
+      hipLaunchKernelGGL((scalar_oneshot_kernel<OP, true>), dim3(grid), dim3(256), 0, stream, rp);
+    else
+      hipLaunchKernelGGL((scalar_oneshot_kernel<OP, false>), dim3(grid), dim3(256), 0, stream, rp);
+    return;
+  }
   const dim3 block(64 * rp.wpb);
   if (check) {
     if (V == 2)
@@ -393,35 +491,46 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   rp.all_defined = prm.all_defined;
   rp.undef = prm.undef;
   rp.n_undefined = prm.n_undefined;
-  const int grid = rp.per_xcd * 8;
+  int grid = rp.per_xcd * 8;
   const size_t lds = (size_t)rp.R * 1024 * V * 3;
   const bool check = !prm.every_level_all_defined;
+  int form = V;
+  // a small launch (fewer than 2048 waves even with 8-row bands) takes the one-shot form
+  if (!std::getenv("MIFC_SCALAR_ROWS_R") && (long)prm.nlev * ((ny - 2 + 7) / 8) * rp.nwc < 2048) {
+    rp.uB = (ny - 2 + 3) / 4;
+    rp.uW = (nx + 255) / 256;
+    const long units = (long)prm.nlev * rp.uB * rp.uW;
+    if (units <= 0x7fffffffL) {
+      grid = (int)units;
+      form = 0;
+    }
+  }
 
   *handled = true;
   switch (op) {
   case ST_GRAD_X:
-    launch_op<ST_GRAD_X>(rp, check, V, grid, lds, stream);
+    launch_op<ST_GRAD_X>(rp, check, form, grid, lds, stream);
     break;
   case ST_GRAD_Y:
-    launch_op<ST_GRAD_Y>(rp, check, V, grid, lds, stream);
+    launch_op<ST_GRAD_Y>(rp, check, form, grid, lds, stream);
     break;
   case ST_GRAD_ABS:
-    launch_op<ST_GRAD_ABS>(rp, check, V, grid, lds, stream);
+    launch_op<ST_GRAD_ABS>(rp, check, form, grid, lds, stream);
     break;
   case ST_GRAD_LAP:
-    launch_op<ST_GRAD_LAP>(rp, check, V, grid, lds, stream);
+    launch_op<ST_GRAD_LAP>(rp, check, form, grid, lds, stream);
     break;
   case ST_GWIND_X:
-    launch_op<ST_GWIND_X>(rp, check, V, grid, lds, stream);
+    launch_op<ST_GWIND_X>(rp, check, form, grid, lds, stream);
     break;
   case ST_GWIND_Y:
-    launch_op<ST_GWIND_Y>(rp, check, V, grid, lds, stream);
+    launch_op<ST_GWIND_Y>(rp, check, form, grid, lds, stream);
     break;
   case ST_GVORT:
-    launch_op<ST_GVORT>(rp, check, V, grid, lds, stream);
+    launch_op<ST_GVORT>(rp, check, form, grid, lds, stream);
     break;
   default:
-    launch_op<ST_IGWIND>(rp, check, V, grid, lds, stream);
+    launch_op<ST_IGWIND>(rp, check, form, grid, lds, stream);
     break;
   }
   return hipGetLastError();
