@@ -422,7 +422,7 @@ level_done:
 // workgroup and with the next row block on the same XCD); in exchange every
 // wave has its whole traffic in flight at once and lives for one memory
 // round trip, like a streaming copy.
-template <bool CHECK, bool WANT_V, bool WANT_D, bool NT>
+template <bool CHECK, bool WANT_V, bool WANT_D, bool NT, bool JAC = false>
 __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P)
 {
   const int wave = threadIdx.x >> 6;
@@ -480,11 +480,21 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
   for (int k = 0; k < 4; ++k) {
     const float vw = vcx[k], ve = vcx[k + 2], uw = ucx[k], ue = ucx[k + 2];
     bool ok = true;
-    if (CHECK)
+    if (CHECK && !JAC)
       ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef)); // :1861, :1927
+    if (CHECK && JAC) // :2443-2444: all eight neighbours
+      ok = all || (is_def(uw, undef) && is_def(ue, undef) && is_def(us[k], undef) && is_def(un[k], undef) && is_def(vw, undef) && is_def(ve, undef) &&
+                   is_def(vs[k], undef) && is_def(vn[k], undef));
     zv[k] = 0.f;
     zd[k] = 0.f;
-    if (WANT_V)
+    if (JAC) { // :2445-2449: four float-rounded partials, float combination (u = field1, v = field2)
+      const double hx = 0.5 * (double)xm4[k], hy = 0.5 * (double)ym4[k];
+      const float df1dx = (float)(hx * (double)(ue - uw));
+      const float df1dy = (float)(hy * (double)(un[k] - us[k]));
+      const float df2dx = (float)(hx * (double)(ve - vw));
+      const float df2dy = (float)(hy * (double)(vn[k] - vs[k]));
+      zv[k] = ok ? (df1dx * df2dy - df1dy * df2dx) : undef;
+    } else if (WANT_V)
       zv[k] = ok ? f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]) : undef;
     if (WANT_D)
       zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]) : undef;
@@ -846,7 +856,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     // bands put more waves on the chip, and their halo re-reads stay in L2.
     // One 1440x720 level: 8-row bands 270 waves, 2-row bands 1077; 8 levels (a chunk of the host pipeline) keep 8.
     const long rows = prm.ny_local, wcols = (nx + 256 * t.V - 1) / (256 * t.V), waves_per_band = (long)prm.nlev * wcols;
-    if (waves_per_band * ((rows + t.R - 1) / t.R) < 2048 && prm.op != ST_ABSVORT && prm.op != ST_JACOBIAN) {
+    if (waves_per_band * ((rows + t.R - 1) / t.R) < 2048 && prm.op != ST_ABSVORT) {
       // ... and the wind operators have a form without any row loop: one 1440x720 level takes 6.7 us
       // (7.5 us with tests and counts) instead of 7.3 (10.8) with 2-row bands, 12.9 (21.6) with 8-row bands
       t.K = 1;
@@ -907,6 +917,21 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   int grid = rp.per_xcd * 8;
 
   *handled = true;
+  if (t.K == 1 && prm.op == ST_JACOBIAN) { // one-shot form of the Jacobian
+    rp.uB = (rp.hi - rp.lo + 3) / 4;
+    rp.uW = (nx + 255) / 256;
+    const long units = (long)prm.nlev * rp.uB * rp.uW;
+    if (units <= 0x3fffffffL) {
+      rp.n_logical = (int)units;
+      rp.per_xcd = (rp.n_logical + 7) / 8;
+      grid = rp.per_xcd * 8;
+      if (prm.every_level_all_defined)
+        hipLaunchKernelGGL((vortdiv_oneshot_kernel<false, true, false, true, true>), dim3(grid), dim3(256), 0, stream, rp);
+      else
+        hipLaunchKernelGGL((vortdiv_oneshot_kernel<true, true, false, true, true>), dim3(grid), dim3(256), 0, stream, rp);
+      return hipGetLastError();
+    }
+  }
   if (t.K == 1 && !rp.fc && prm.op != ST_JACOBIAN) { // one-shot form: units are (level, block of 4 rows, 256-column segment)
     rp.uB = (rp.hi - rp.lo + 3) / 4;
     rp.uW = (nx + 255) / 256;
