@@ -495,8 +495,10 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   const size_t lds = (size_t)rp.R * 1024 * V * 3;
   const bool check = !prm.every_level_all_defined;
   int form = V;
-  // a small launch (fewer than 2048 waves even with 8-row bands) takes the one-shot form
-  if (!std::getenv("MIFC_SCALAR_ROWS_R") && (long)prm.nlev * ((ny - 2 + 7) / 8) * rp.nwc < 2048) {
+  // a small launch (fewer than 2048 waves even with 8-row bands) takes the one-shot form, and so do one or
+  // two levels of any size: their row-walking workgroups would be single waves holding a 48-KiB tile of map
+  // factors, three to a CU
+  if (!std::getenv("MIFC_SCALAR_ROWS_R") && ((long)prm.nlev * ((ny - 2 + 7) / 8) * rp.nwc < 2048 || prm.nlev <= 2)) {
     rp.uB = (ny - 2 + 3) / 4;
     rp.uW = (nx + 255) / 256;
     const long units = (long)prm.nlev * rp.uB * rp.uW;

@@ -856,10 +856,15 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     // bands put more waves on the chip, and their halo re-reads stay in L2.
     // One 1440x720 level: 8-row bands 270 waves, 2-row bands 1077; 8 levels (a chunk of the host pipeline) keep 8.
     const long rows = prm.ny_local, wcols = (nx + 256 * t.V - 1) / (256 * t.V), waves_per_band = (long)prm.nlev * wcols;
-    if (waves_per_band * ((rows + t.R - 1) / t.R) < 2048 && prm.op != ST_ABSVORT) {
-      // ... and the wind operators have a form without any row loop: one 1440x720 level takes 6.7 us
-      // (7.5 us with tests and counts) instead of 7.3 (10.8) with 2-row bands, 12.9 (21.6) with 8-row bands
-      t.K = 1;
+    const bool small = waves_per_band * ((rows + t.R - 1) / t.R) < 2048;
+    if (prm.op != ST_ABSVORT && (small || prm.nlev <= 2)) {
+      // ... and the wind operators have forms without any row loop.  Small launches: one 1440x720 level takes
+      // 6.7 us (7.5 us with tests and counts) instead of 7.3 (10.8) with 2-row bands, 12.9 (21.6) with 8-row
+      // bands.  One or two levels of any size: the row-walking workgroup would be one or two waves holding a
+      // 32-KiB map-factor tile (5 waves per CU); a 4000x4000 level straight from HBM runs at 48 % of peak
+      // that way, 66 % one-shot, 69 % as one-shot tiles with the row reuse in LDS
+      // (profiles/r01/other_configs.jsonl, cold numbers).
+      t.K = (small || prm.op == ST_JACOBIAN) ? 1 : 2;
     }
     while (t.R > 2 && waves_per_band * ((rows + t.R - 1) / t.R) < 2048)
       t.R /= 2;

@@ -451,9 +451,14 @@ def test_vortdiv_enqueue_counts(gpu_ctx, oracle):
 # ------------------------------------------------------------------ row slabs
 @pytest.mark.parametrize("nx,ny,nslab", [(64, 40, 4), (260, 23, 3), (512, 64, 8), (33, 17, 2)])
 @pytest.mark.parametrize("mode", ["all", "some"])
-def test_vortdiv_row_slabs_equal_whole_field(gpu_ctx, oracle, nx, ny, nslab, mode):
-    """Config 4 decomposition exercised on one GPU with a loop-back halo 'exchange'."""
+@pytest.mark.parametrize("tune", [None, "K=2", "R=8"])
+def test_vortdiv_row_slabs_equal_whole_field(gpu_ctx, oracle, nx, ny, nslab, mode, tune, monkeypatch):
+    """Config 4 decomposition exercised on one GPU with a loop-back halo 'exchange' (the launcher picks the
+    kernel form by launch size: the default, the one-shot tiles and the row-walking form all have to agree)."""
     import torch
+
+    if tune is not None:
+        monkeypatch.setenv("MIFC_VORTDIV_TUNE", tune)
 
     import mi_fieldcalc_amd as fc
     import mi_fieldcalc_amd.synth as synth
