@@ -165,7 +165,15 @@ def main():
     add("log10Field", 8, 0, lambda: ctx.log10Field(tall(t), fdefined=ALLD, out=o_t), "log10Field", [h["t"]])
     # ---- 8f-4: reductions over the batch's levels taken as ensemble members of one 1440x720 field
     nm = min(NLEV, 51)
-    members = [t[k] for k in range(nm)]
+    # 51 members are 211 MB -- they would sit in the 256 MB Infinity Cache between calls: every call takes the
+    # next of four member sets (t, q-, u-, v-derived fields of the same size), 0.85 GB in rotation
+    msets = [[src[k] for k in range(nm)] for src in (t, (t + 1.0).contiguous(), (t - 2.0).contiguous(), (t + 3.0).contiguous())] if NLEV >= nm else [[t[k] for k in range(nm)]]
+    state = {"k": 0}
+
+    def next_members():
+        state["k"] += 1
+        return msets[state["k"] % len(msets)]
+
     hm = [t[k].cpu().numpy() for k in range(min(nm, 8))]
     o1 = out[0]
 
@@ -185,9 +193,9 @@ def main():
         print(json.dumps(rec), flush=True)
 
     mflags = [fc.ALL_DEFINED] * nm
-    add_ens("meanValue (%d members)" % nm, lambda: ctx.meanValue(members, mflags, out=o1), "meanValue", [hm, mflags[:len(hm)]])
-    add_ens("stddevValue (%d members)" % nm, lambda: ctx.stddevValue(members, mflags, out=o1), "stddevValue", [hm, mflags[:len(hm)]])
-    add_ens("probability>280 (%d members)" % nm, lambda: ctx.probability(1, members, mflags, [280.0], out=o1), "probability",
+    add_ens("meanValue (%d members)" % nm, lambda: ctx.meanValue(next_members(), mflags, out=o1), "meanValue", [hm, mflags[:len(hm)]])
+    add_ens("stddevValue (%d members)" % nm, lambda: ctx.stddevValue(next_members(), mflags, out=o1), "stddevValue", [hm, mflags[:len(hm)]])
+    add_ens("probability>280 (%d members)" % nm, lambda: ctx.probability(1, next_members(), mflags, [280.0], out=o1), "probability",
             [1, hm, mflags[:len(hm)], [280.0]])
     print()
     print("%-32s %9s %9s %11s %7s %9s %13s" % ("operator (1440x720x%d)" % NLEV, "call ms", "kernel ms", "Mcells/s", "frac", "k.frac", "CPU Mcells/s"))
