@@ -422,7 +422,7 @@ level_done:
 // workgroup and with the next row block on the same XCD); in exchange every
 // wave has its whole traffic in flight at once and lives for one memory
 // round trip, like a streaming copy.
-template <bool CHECK, bool WANT_V, bool WANT_D, bool NT, bool JAC = false>
+template <bool CHECK, bool WANT_V, bool WANT_D, bool NT, bool JAC = false, bool ABSV = false>
 __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P)
 {
   const int wave = threadIdx.x >> 6;
@@ -461,6 +461,9 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
   const v4f un = load4(u + o + nx), us = load4(u + o - nx);
   const v4f vn = load4(v + o + nx), vs = load4(v + o - nx);
   const v4f xm4 = load4(P.xm + o), ym4 = load4(P.ym + o);
+  v4f fc4 = xm4;
+  if (ABSV)
+    fc4 = load4(P.fc + o);
   long e = base + edge_col;
   e = e < P.idx_lo ? P.idx_lo : (e > P.idx_hi ? P.idx_hi : e);
   const float eu = u[e], ev = v[e];
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
       const float df2dy = (float)(hy * (double)(vn[k] - vs[k]));
       zv[k] = ok ? (df1dx * df2dy - df1dy * df2dx) : undef;
     } else if (WANT_V)
-      zv[k] = ok ? f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]) : undef;
+      zv[k] = ok ? (ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k])) : undef;
     if (WANT_D)
       zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]) : undef;
     if (CHECK && !ok && act)
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
 // ITS row once (u, v, map factors, one edge scalar), parks u and v in LDS,
 // and after one barrier the RB inner waves take the rows above and below from
 // there.  Loads per cell: (RB+2)/RB instead of the 3 of K=1, no row loop.
-template <bool CHECK, bool WANT_V, bool WANT_D, bool NT, int RB>
+template <bool CHECK, bool WANT_V, bool WANT_D, bool NT, int RB, bool ABSV = false>
 __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsParams P)
 {
   __shared__ v4f su[RB + 2][64];
@@ -590,11 +593,13 @@ __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsP
   const long base = (long)jl * nx;
   const long o = base + col_c;
   const v4f uc = load4(u + o), vc = load4(v + o);
-  v4f xm4 = uc, ym4 = uc;
+  v4f xm4 = uc, ym4 = uc, fc4 = uc;
   float eu = 0.f, ev = 0.f;
   if (computes) {
     xm4 = load4(P.xm + o);
     ym4 = load4(P.ym + o);
+    if (ABSV)
+      fc4 = load4(P.fc + o);
     long e = base + edge_col;
     e = e < P.idx_lo ? P.idx_lo : (e > P.idx_hi ? P.idx_hi : e);
     eu = u[e];
@@ -628,7 +633,7 @@ __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsP
     zv[k] = 0.f;
     zd[k] = 0.f;
     if (WANT_V)
-      zv[k] = ok ? f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]) : undef;
+      zv[k] = ok ? (ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k])) : undef;
     if (WANT_D)
       zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]) : undef;
     if (CHECK && !ok && act)
@@ -857,7 +862,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     // One 1440x720 level: 8-row bands 270 waves, 2-row bands 1077; 8 levels (a chunk of the host pipeline) keep 8.
     const long rows = prm.ny_local, wcols = (nx + 256 * t.V - 1) / (256 * t.V), waves_per_band = (long)prm.nlev * wcols;
     const bool small = waves_per_band * ((rows + t.R - 1) / t.R) < 2048;
-    if (prm.op != ST_ABSVORT && (small || prm.nlev <= 2)) {
+    if (small || prm.nlev <= 2) {
       // ... and the wind operators have forms without any row loop.  Small launches: one 1440x720 level takes
       // 6.7 us (7.5 us with tests and counts) instead of 7.3 (10.8) with 2-row bands, 12.9 (21.6) with 8-row
       // bands.  One or two levels of any size: the row-walking workgroup would be one or two waves holding a
@@ -922,6 +927,30 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   int grid = rp.per_xcd * 8;
 
   *handled = true;
+  if ((t.K == 1 || t.K == 2) && rp.fc) { // one-shot forms of absvort (relvort + the Coriolis parameter)
+    const bool tiles = t.K == 2;
+    rp.uB = (rp.hi - rp.lo + (tiles ? 7 : 3)) / (tiles ? 8 : 4);
+    rp.uW = (nx + 255) / 256;
+    const long units = (long)prm.nlev * rp.uB * rp.uW;
+    if (units <= 0x3fffffffL) {
+      rp.n_logical = (int)units;
+      rp.per_xcd = (rp.n_logical + 7) / 8;
+      grid = rp.per_xcd * 8;
+      const bool chk = !prm.every_level_all_defined;
+      if (tiles) {
+        if (chk)
+          hipLaunchKernelGGL((vortdiv_tile_kernel<true, true, false, true, 8, true>), dim3(grid), dim3(640), 0, stream, rp);
+        else
+          hipLaunchKernelGGL((vortdiv_tile_kernel<false, true, false, true, 8, true>), dim3(grid), dim3(640), 0, stream, rp);
+      } else {
+        if (chk)
+          hipLaunchKernelGGL((vortdiv_oneshot_kernel<true, true, false, true, false, true>), dim3(grid), dim3(256), 0, stream, rp);
+        else
+          hipLaunchKernelGGL((vortdiv_oneshot_kernel<false, true, false, true, false, true>), dim3(grid), dim3(256), 0, stream, rp);
+      }
+      return hipGetLastError();
+    }
+  }
   if (t.K == 1 && prm.op == ST_JACOBIAN) { // one-shot form of the Jacobian
     rp.uB = (rp.hi - rp.lo + 3) / 4;
     rp.uW = (nx + 255) / 256;

@@ -84,6 +84,17 @@ def test_shapiro_filter_one_launch_and_four(gpu_ctx, oracle, fused, monkeypatch)
             _check_case(gpu_ctx, oracle, case, device=(nx % 8 == 0))
 
 
+@pytest.mark.parametrize("tune", ["K=1", "K=2", "R=8", "R=2,WPB=1"])
+def test_single_field_wind_operators_in_every_kernel_form(gpu_ctx, oracle, tune, monkeypatch):
+    """relvort / divergence / absvort / jacobian through the C ABI's single-field calls: the launcher picks the
+    one-shot, the one-shot-tile or the row-walking form by launch size; forced here, all give the reference."""
+    monkeypatch.setenv("MIFC_VORTDIV_TUNE", tune)
+    ops = ("relvort", "divergence", "absvort", "jacobian")
+    for case in cases.stencil_cases(grids=[(8, 3), (64, 48), (260, 11), (516, 37)]):
+        if case["op"] in ops:
+            _check_case(gpu_ctx, oracle, case, device=True)
+
+
 def test_elementwise_host_pointers(gpu_ctx, oracle):
     for case in cases.ewise_cases():
         _check_case(gpu_ctx, oracle, case, device=False)
