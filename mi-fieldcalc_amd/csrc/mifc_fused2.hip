@@ -178,8 +178,9 @@ __device__ __attribute__((noinline)) float absdelt_filled_at(const Fused2Params&
 }
 
 // The cells of columns 0 and nx-1, rows 1..ny-2: only their contribution to the counts (their values
-// are fill copies).  Run by a few extra workgroups at the end of the grid; lane = (row, side); everything comes from global memory, with the neighbours the
-// flat loop of the reference sees: west of column 0 is (nx-1, j-1), east of column nx-1 is (0, j+1).
+// are fill copies).  Run by a few extra workgroups at the end of the grid; lane = (row, side);
+// everything comes from global memory, with the neighbours the flat loop of the reference sees:
+// west of column 0 is (nx-1, j-1), east of column nx-1 is (0, j+1).
 template <int OP, bool CHECK>
 __device__ __forceinline__ void edge_count_cells(const Fused2Params& P, const int first, const int stride)
 {
