@@ -101,15 +101,41 @@ __device__ __forceinline__ void row6(const float* row, int p, float (&v)[6])
   v[5] = row[p + 4];
 }
 
+// ---- undefined values as NaN inside the tiles of the tested TFP variant
+// is_def(x) = "x is not NaN and x != undef" costs two compares per value and every value is tested by up to
+// eight cells.  The tested TFP tiles therefore replace undefined values by NaN once, when a row enters LDS
+// (the source rows as they land, |grad| rows as they are stored); after that "is one of these undefined"
+// is "is one of these NaN", one v_cmp_u_f32 per PAIR of values.  A cell that passes its tests computes with
+// exactly the values the reference computes with; a cell that fails becomes undef either way.
+__device__ __forceinline__ float canon_nan(float x, float undef)
+{
+  return is_def(x, undef) ? x : __builtin_nanf("");
+}
+__device__ __forceinline__ float4 canon_nan4(float4 q, float undef)
+{
+  return make_float4(canon_nan(q.x, undef), canon_nan(q.y, undef), canon_nan(q.z, undef), canon_nan(q.w, undef));
+}
+__device__ __forceinline__ bool either_nan(float a, float b)
+{
+  return __builtin_isunordered(a, b);
+}
+
 // ---- the point formulas, shared with the edge-count kernel
 // gradient compute 3, FieldCalculations.cc:2037-2046
-template <bool CHECK>
+// CANON: the inputs carry undefined values as NaN (see above) and so does the result
+template <bool CHECK, bool CANON = false>
 __device__ __forceinline__ float tfp_absdelt(float s, float w, float e, float n, float xm, float ym, float undef, bool& ok)
 {
-  ok = !CHECK || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef));
+  if (CANON)
+    ok = !(either_nan(s, w) || either_nan(e, n));
+  else
+    ok = !CHECK || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef));
   const float dfdx = (float)(0.5 * (double)xm * (double)(e - w));
   const float dfdy = (float)(0.5 * (double)ym * (double)(n - s));
-  return ok ? absval(dfdx, dfdy) : undef;
+  const float g = absval(dfdx, dfdy);
+  if (CANON) // a computed NaN, or a computed value that happens to equal undef, is undefined to the next pass (:2290)
+    return (ok && is_def(g, undef)) ? g : __builtin_nanf("");
+  return ok ? g : undef;
 }
 // plevelgwind_xcomp :660-663 (tests only if the caller's flag is not ALL_DEFINED),
 // plevelgwind_ycomp :693-698 (always tests: the x pass hands it NONE_DEFINED, :664)
@@ -124,12 +150,16 @@ __device__ __forceinline__ void qvec_gwind(float s, float w, float e, float n, f
   vg = ok ? v : undef;
 }
 // thermalFrontParameter :2290-2298
-template <bool CHECK>
+template <bool CHECK, bool CANON = false>
 __device__ __forceinline__ float tfp_point(float ts, float tw, float te, float tn, float gs, float gw, float g, float ge, float gn, float xm, float ym,
                                            float undef, bool& ok, bool& rejected_by_test_only)
 {
-  const bool def = !CHECK || (is_def(ts, undef) && is_def(tw, undef) && is_def(te, undef) && is_def(tn, undef) && is_def(gs, undef) &&
-                              is_def(gw, undef) && is_def(g, undef) && is_def(ge, undef) && is_def(gn, undef));
+  bool def;
+  if (CANON)
+    def = !(either_nan(ts, tw) || either_nan(te, tn) || either_nan(gs, gw) || either_nan(ge, gn) || g != g);
+  else
+    def = !CHECK || (is_def(ts, undef) && is_def(tw, undef) && is_def(te, undef) && is_def(tn, undef) && is_def(gs, undef) && is_def(gw, undef) &&
+                     is_def(g, undef) && is_def(ge, undef) && is_def(gn, undef));
   ok = def && g != 0;
   rejected_by_test_only = CHECK && !def && g != 0;
   const double hx = 0.5 * (double)xm, hy = 0.5 * (double)ym;
@@ -246,6 +276,7 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
     edge_count_cells<OP, CHECK>(P, ((int)blockIdx.x - n_main) * 64 + (int)threadIdx.x, ((int)gridDim.x - n_main) * 64);
     return;
   }
+  constexpr bool CANON = TFP && CHECK; // undefined values travel as NaN inside the tiles
   constexpr int RA = TFP ? 4 : 3;
   constexpr int ROWS = TFP ? RA + 3 : RA + 3 + 3;
   __shared__ float4 lds4[ROWS * TS / 4];
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
 
   const size_t ccol = (size_t)(loadable ? xq : tile * TW); // other lanes load a valid address and use nothing
   if (loadable && rs >= 0)
-    *reinterpret_cast<float4*>(ringA + (rs % RA) * TS + p) = ld4(P.a + (size_t)rs * nx + ccol);
+    *reinterpret_cast<float4*>(ringA + (rs % RA) * TS + p) = CANON ? canon_nan4(ld4(P.a + (size_t)rs * nx + ccol), undef) : ld4(P.a + (size_t)rs * nx + ccol);
   unsigned int n1 = 0, n2 = 0, n2c = 0;
 
   struct RowMaps // what a lane keeps of a row beyond the iteration that loads it: map factors, and the Q-vector's temperature
@@ -322,7 +353,7 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           bool ok;
-          g[k] = tfp_absdelt<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], undef, ok);
+          g[k] = tfp_absdelt<CHECK, CANON>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], undef, ok);
           const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3); // counted by edge_count_cells
           if (counted && !edge_cell && !ok)
             ++n1;
@@ -382,7 +413,7 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           bool ok, by_test;
-          o[k] = tfp_point<CHECK>(ts[k], tc[k], tc[k + 2], tn[k], gs[k], gc[k], gc[k + 1], gc[k + 2], gn[k], xm[k], ym[k], undef, ok, by_test);
+          o[k] = tfp_point<CHECK, CANON>(ts[k], tc[k], tc[k + 2], tn[k], gs[k], gc[k], gc[k + 1], gc[k + 2], gn[k], xm[k], ym[k], undef, ok, by_test);
           // the cells of columns 0 / nx-1 need wrapped neighbours for their tests: the edge kernel counts
           // them -- unless nothing is tested, then |grad| != 0 of the filled value is all there is
           const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
@@ -429,7 +460,7 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
     __builtin_amdgcn_s_waitcnt(0x0F70);
     if (loadable) {
       if (load_a)
-        *reinterpret_cast<float4*>(ringA + ((r + 1) % RA) * TS + p) = pa;
+        *reinterpret_cast<float4*>(ringA + ((r + 1) % RA) * TS + p) = CANON ? canon_nan4(pa, undef) : pa;
     }
     lds_rows_visible();
     if (!TFP)
