@@ -12,13 +12,21 @@ one such member (members are independent: no data-path collective, weak
 scaling); `value` = cells processed by all ranks / max-over-ranks wall time.
 
 The JSON line also carries
+  verified     : before anything is timed, sampled levels of the GPU's rvort and
+                 diverg are compared bit for bit with the reference CPU path (the
+                 same calls cpu_baseline times) -- both the ALL_DEFINED fast path
+                 and the tested SOME_DEFINED variant; a mismatch aborts the run;
   roofline     : algorithmic bytes (16 B/cell + map factors once per batch)
                  over the kernel's average duration measured with HIP events
                  on the launch stream, against the 8 TB/s HBM3E peak;
+  check_variant: the same launch with per-cell undefined tests and per-level
+                 counts (SOME_DEFINED inputs), timed right after the headline;
   cpu_baseline : the reference CPU path (oracle/_ref, compiled from the
                  reference's own sources; or the bit-exact restatement if that
                  library is not present) calling relvort then divergence per
                  level on this host, on a bounded sample.
+The CPU library is only ever the checker / the reported baseline: nothing inside a
+timed region touches it.
 """
 import argparse
 import json
@@ -39,6 +47,39 @@ def algorithmic_bytes(nx, ny, nlev):
     return nx * ny * nlev * 16 + 2 * nx * ny * 4
 
 
+def _cpu_library():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpulib
+
+    which = "ref" if cpulib.available("ref") else "oracle"
+    return cpulib, which, cpulib.CpuLib(which)
+
+
+def verify_against_cpu(levels, u_levels, v_levels, xm, ym, rv_levels, dg_levels, flag, counts=None):
+    """Checker leg (never timed): the reference CPU path on the sampled levels, relvort then
+    divergence like cpu_baseline(); the GPU's results must equal it bit for bit (a NaN matches a
+    NaN: its payload is an ISA property).  Returns the name of the CPU library used."""
+    import numpy as np
+
+    cpulib, which, lib = _cpu_library()
+
+    def same(a, b):
+        an, bn = np.isnan(a), np.isnan(b)
+        return bool(np.array_equal(an, bn) and np.array_equal(a.view(np.uint32)[~an], b.view(np.uint32)[~bn]))
+
+    for k, l in enumerate(levels):
+        for name, got in (("relvort", rv_levels[k]), ("divergence", dg_levels[k])):
+            ok, expect, f = lib.call(name, NX, NY, u_levels[k], v_levels[k], xm, ym, fdefined=flag)
+            if not (ok and same(got, expect)):
+                raise SystemExit("bench.py: GPU %s of level %d differs from the CPU reference path (%s) -- nothing is timed" % (name, l, which))
+            if counts is not None:
+                import mi_fieldcalc_amd as fc
+
+                if fc.classify(int(counts[k]), NX * NY - 2 * NX) != f:
+                    raise SystemExit("bench.py: flag of level %d differs from the CPU reference path" % l)
+    return "reference" if which == "ref" else "port"
+
+
 def cpu_baseline(seconds_target=10.0):
     """Reference CPU path timed on this host.  The oracle / reference build is used
     here ONLY as the reported baseline, never on the product path."""
@@ -46,12 +87,9 @@ def cpu_baseline(seconds_target=10.0):
 
     import numpy as np
 
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import cpulib
     import mi_fieldcalc_amd.synth as synth
 
-    which = "ref" if cpulib.available("ref") else "oracle"
-    lib = cpulib.CpuLib(which)
+    cpulib, which, lib = _cpu_library()
     kind = "reference" if which == "ref" else "port"
     nlev = NLEV
     xm, ym, _ = synth.grid_maps(NX, NY)
@@ -91,24 +129,40 @@ def cpu_baseline(seconds_target=10.0):
             extras["cpu_model"] = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
     except OSError:
         pass
-    # whole host: outer thread-per-level loop over serial reference calls (ctypes releases the GIL)
+    # whole host: every hardware thread busy -- the levels are cut into row pieces (serial reference calls on
+    # sub-fields that overlap by the two rows a stencil needs; ctypes releases the GIL), 2 pieces per level on a
+    # 256-thread host = 274 tasks
     workers = os.cpu_count() or 1
-    outs = [np.empty((NY, NX), np.float32) for _ in range(workers)]
+    pieces = max(1, -(-workers // nlev))
+    rows = -(-(NY - 2) // pieces)
+    tasks = []
+    for l in range(nlev):
+        for k in range(pieces):
+            j0 = k * rows  # piece = computed rows j0+1 .. j0+rows, handed to the reference as a field of rows j0 .. j0+rows+1
+            nyp = min(rows + 2, NY - j0)
+            if nyp >= 3:
+                tasks.append((l, j0, nyp))
+    outs = [np.empty((rows + 2, NX), np.float32) for _ in range(workers)]
 
-    def chunk(w):
-        for l in range(w, nlev, workers):
-            one_level(l, outs[w])
+    def piece(w):
+        for l, j0, nyp in tasks[w::workers]:
+            fd = ctypes.c_int(0)
+            relvort(NX, nyp, u[l, j0:].ctypes.data, v[l, j0:].ctypes.data, xm[j0:].ctypes.data, ym[j0:].ctypes.data, outs[w].ctypes.data,
+                    ctypes.addressof(fd), 1e35)
+            fd = ctypes.c_int(0)
+            diverg(NX, nyp, u[l, j0:].ctypes.data, v[l, j0:].ctypes.data, xm[j0:].ctypes.data, ym[j0:].ctypes.data, outs[w].ctypes.data,
+                   ctypes.addressof(fd), 1e35)
 
     with cf.ThreadPoolExecutor(workers) as ex:
-        list(ex.map(chunk, range(workers)))  # warm-up
+        list(ex.map(piece, range(workers)))  # warm-up
         t0 = time.perf_counter()
         passes = 0
         while time.perf_counter() - t0 < seconds_target / 2:
-            list(ex.map(chunk, range(workers)))
+            list(ex.map(piece, range(workers)))
             passes += 1
         dt = time.perf_counter() - t0
     extras["all_cores"] = {"value": round(n * nlev * passes / dt / 1e6, 1), "unit": "Mcells/s", "cores": workers, "kind": kind,
-                           "sample": "%d passes, thread per level" % passes}
+                           "sample": "%d passes, %d tasks (%d row pieces per level) over %d threads" % (passes, len(tasks), pieces, min(workers, len(tasks)))}
     # the library's own OpenMP path (ENABLE_OPENMP=ON), capped at 8 threads by the reference (openmp_tools.cc:54,65)
     if which == "ref" and cpulib.available("ref_omp"):
         os.environ.setdefault("OMP_NUM_THREADS", "8")
@@ -154,7 +208,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--check", action="store_true", help="also time the SOME_DEFINED (per-cell test + count) variant")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison with the CPU reference path before timing (profiling runs)")
+    ap.add_argument("--no-check-variant", action="store_true", help="do not time the SOME_DEFINED (per-cell tests + counts) variant")
+    ap.add_argument("--check", action="store_true", help="(kept for compatibility: the tested variant is timed by default)")
+    ap.add_argument("--level-stride", type=int, default=None, help="floats between levels (default: the library's mifc_batch_level_stride)")
     args = ap.parse_args()
 
     import numpy as np
@@ -185,16 +242,20 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- this rank's batch: one ensemble member = 137 levels, generated in HBM
-    xm, ym, _ = synth.grid_maps(NX, NY)
-    dxm, dym = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
-    du, dv = synth.device_wind(NX, NY, NLEV, SEED + 17 * rank, dev)
-    rv = torch.empty_like(du)
-    dg = torch.empty_like(du)
-    flags = np.full(NLEV, fc.ALL_DEFINED, np.int32)
-    counts = torch.zeros(NLEV, dtype=torch.int64, device=dev)
-
     ctx = fc.Context(dev_index)
     ctx.use_torch_stream()
+    xm, ym, _ = synth.grid_maps(NX, NY)
+    dxm, dym = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
+    # the batch lives in the library's layout: [nlev][ny][nx] with the levels mifc_batch_level_stride() floats apart
+    level_stride = args.level_stride or ctx.batch_level_stride(NX, NY)
+    du, dv, rv, dg = (ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride) for _ in range(4))
+    su, sv = synth.device_wind(NX, NY, NLEV, SEED + 17 * rank, dev)
+    du.copy_(su)
+    dv.copy_(sv)
+    del su, sv
+    torch.cuda.empty_cache()
+    flags = np.full(NLEV, fc.ALL_DEFINED, np.int32)
+    counts = torch.zeros(NLEV, dtype=torch.int64, device=dev)
 
     def step(check=False):
         if check:
@@ -223,6 +284,28 @@ def main():
         wall = time.perf_counter() - t0
         kern_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
         return wall, kern_ms
+
+    # ---- checker leg, before anything is timed: sampled levels against the reference CPU path
+    verified, verified_kind = None, None
+    sample = (0, NLEV // 2, NLEV - 1)
+    if rank == 0 and not args.no_verify:
+        def grab(t):
+            return [t[l].cpu().numpy() for l in sample]
+
+        step()
+        torch.cuda.synchronize()
+        verified_kind = verify_against_cpu(sample, grab(du), grab(dv), xm, ym, grab(rv), grab(dg), fc.ALL_DEFINED)
+        # the tested variant on inputs that carry undefined values (restored afterwards)
+        keep = [(l, du[l, 100:110, 200:260].clone()) for l in sample]
+        for l in sample:
+            du[l, 100:110, 200:260] = float(fc.UNDEF)
+        step(True)
+        torch.cuda.synchronize()
+        cs = counts.cpu().numpy()
+        verify_against_cpu(sample, grab(du), grab(dv), xm, ym, grab(rv), grab(dg), fc.SOME_DEFINED, counts=[cs[l] for l in sample])
+        for l, blk in keep:
+            du[l, 100:110, 200:260] = blk
+        verified = True
 
     for _ in range(args.warmup):
         step()
@@ -255,7 +338,10 @@ def main():
             "workload": "1440x720x137 float32 fused relvort+divergence (BASELINE.json configs[2]), one 137-level ensemble member per GPU, inputs ALL_DEFINED and resident in HBM",
             "nx": NX, "ny": NY, "nlev": NLEV, "members_per_gpu": 1, "sharding": "members across GPUs, no collective",
             "tuning": os.environ.get("MIFC_VORTDIV_TUNE", "default"),
+            "level_stride_floats": int(level_stride),
         },
+        "verified": verified,
+        "verified_against": None if not verified else "%s CPU path, levels %s bit for bit, ALL_DEFINED and SOME_DEFINED (+ flags)" % (verified_kind, list(sample)),
         "roofline": {
             "bound": "hbm",
             "achieved": round(achieved, 1),
@@ -265,18 +351,32 @@ def main():
             "traffic": pmc_traffic(),
             "algorithmic_bytes_per_launch": alg,
             "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
+            "kernel_ms_median": round(float(np.median(kern_ms)), 4),
             "kernel_ms_min": round(float(np.min(kern_ms)), 4),
         },
     }
-    if args.check and rank == 0:
+    if rank == 0 and world == 1 and not args.no_check_variant:
         du[:, 100:110, 200:260] = float(fc.UNDEF)  # some undefined cells so that the count path does real work
         for _ in range(2):
             step(True)
         torch.cuda.synchronize()
-        _, kms = timed(max(5, args.steps // 2), check=True)
-        out["check_variant"] = {"kernel_ms_avg": round(float(np.mean(kms)), 4),
+
+        def timed_check(nsteps):  # no barrier: rank 0 only
+            starts = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps)]
+            ends = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps)]
+            for k in range(nsteps):
+                starts[k].record()
+                step(True)
+                ends[k].record()
+            torch.cuda.synchronize()
+            return [s.elapsed_time(e) for s, e in zip(starts, ends)]
+
+        kms = timed_check(max(10, args.steps))
+        med = float(np.median(kms))
+        out["check_variant"] = {"kernel_ms_avg": round(float(np.mean(kms)), 4), "kernel_ms_median": round(med, 4),
                                 "Mcells_per_s": round(cells_per_step / (float(np.mean(kms)) / 1e3) / 1e6, 1),
-                                "note": "SOME_DEFINED inputs: per-cell undefined tests + per-level counts (memset + kernel)"}
+                                "roofline_frac": round(alg / (float(np.mean(kms)) / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "note": "SOME_DEFINED inputs: per-cell undefined tests + per-level counts (memset + kernel), the variant the parity tests cover"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base, extras = cpu_baseline()
         out["cpu_baseline"] = base

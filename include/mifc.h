@@ -65,9 +65,15 @@ const char* mifc_last_error(const mifc_ctx* ctx);
  * stream.  NULL means HIP's null (default) stream -- which is what PyTorch's
  * default stream is.  mifc_use_own_stream() switches back to the context's own
  * non-blocking stream (the initial state). */
+/* Switching streams is ordered against work already enqueued on the old stream
+ * that still reads context-owned scratch: the new stream waits for it. */
 int mifc_set_stream(mifc_ctx* ctx, void* hip_stream);
 int mifc_use_own_stream(mifc_ctx* ctx);
 int mifc_synchronize(mifc_ctx* ctx);
+/* The library's tuning / diagnostic environment variables (MIFC_*: which of several
+ * equivalent kernel forms runs; none changes a result) are read when a context is
+ * created, never on a call path.  Re-read them (tests, A/B tools). */
+int mifc_reload_env(mifc_ctx* ctx);
 /* Device memory for callers that do not link HIP themselves. */
 void* mifc_device_alloc(mifc_ctx* ctx, size_t bytes);
 int mifc_device_free(mifc_ctx* ctx, void* dptr);
@@ -270,6 +276,17 @@ int mifc_vortdiv_levels(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u,
 int mifc_vortdiv_levels_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
                                 float* rvort, float* diverg, const int* fdefined_in, float undef, unsigned long long* n_undefined_dev);
 
+/* The same with explicit level strides (in floats, multiples of 4, >= nx*ny):
+ * level l of u / v starts at u + l*in_level_stride, of rvort / diverg at
+ * rvort + l*out_level_stride.  A batch whose levels are padded to
+ * mifc_batch_level_stride(nx, ny) floats streams through HBM evenly whatever
+ * nx*ny is (a level size close to a multiple of 4 MiB makes the
+ * eight levels a workgroup walks side by side meet in the same memory channels). */
+size_t mifc_batch_level_stride(int nx, int ny);
+int mifc_vortdiv_levels_strided_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr,
+                                        const float* ymapr, float* rvort, float* diverg, size_t in_level_stride, size_t out_level_stride,
+                                        const int* fdefined_in, float undef, unsigned long long* n_undefined_dev);
+
 /* Any stencil operator over a batch of levels (generic form of the call above).
  * op selects the reference function:
  *   MIFC_OP_RELVORT .cc:1843, _ABSVORT :1875, _DIVERGENCE :1910, _VORTDIV (both),
@@ -324,6 +341,24 @@ int mifc_hlevel_derived_levels_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, 
 int mifc_vortdiv_slab_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int ny_local, const float* u_halo, const float* v_halo,
                               const float* xmapr, const float* ymapr, float* rvort, float* diverg, int fdefined_in, float undef,
                               unsigned long long* n_undefined_dev);
+
+/* The same restricted to the owned rows [row_begin, row_end) of the slab, so that a caller
+ * can overlap the halo exchange with compute: enqueue the exchange, launch
+ * the interior rows [2, ny_local-2) -- they read no halo row --, wait for the exchange on
+ * the stream, launch [0, 2) and [ny_local-2, ny_local).  accumulate_count != 0 leaves
+ * *n_undefined_dev as it is and adds to it (zero it with the first launch of a slab only).
+ * A range must not separate row 0 from row 1 or row ny_global-1 from row ny_global-2 of
+ * the whole field (fillEdges copies one from the other): such a call returns 0. */
+int mifc_vortdiv_slab_rows_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int ny_local, int row_begin, int row_end, const float* u_halo,
+                                   const float* v_halo, const float* xmapr, const float* ymapr, float* rvort, float* diverg, int fdefined_in,
+                                   float undef, unsigned long long* n_undefined_dev, int accumulate_count);
+/* Halo transport for a process that drives several GPUs itself (one context per GPU):
+ * copies n_floats from src_dev (memory of src_ctx's device) to dst_dev (dst_ctx's device)
+ * over xGMI (hipMemcpyPeerAsync), enqueued on dst_ctx's stream and ordered after the work
+ * already queued on src_ctx's stream.  One row of a slab is nx floats.  Processes that own
+ * one GPU each exchange the rows with RCCL send/recv instead (mi-fieldcalc_amd/sharding.py,
+ * tools/bench_multigpu.py); the slab entry points do not care how the halo rows got there. */
+int mifc_halo_copy_enqueue(mifc_ctx* dst_ctx, float* dst_dev, mifc_ctx* src_ctx, const float* src_dev, size_t n_floats);
 
 /* ---- diagnostics ----------------------------------------------------------- */
 /* Bandwidth yardstick: copies src0 -> dst0 and src1 -> dst1 (n_floats each,

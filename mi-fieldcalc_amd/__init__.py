@@ -36,11 +36,17 @@ def _is_torch(x):
 
 
 class _Arg:
-    """Address + keep-alive of one field argument."""
+    """Address + keep-alive of one field argument.
 
-    __slots__ = ("addr", "keep", "device", "shape")
+    levels=True accepts a (nlev, ny, nx) device tensor whose levels are padded
+    (stride(0) >= ny*nx, every level itself contiguous): ``lstride`` is that
+    level stride in floats.  output=True refuses host arrays that would have to
+    be converted (the caller's array would never be written)."""
 
-    def __init__(self, x, allow_none=False):
+    __slots__ = ("addr", "keep", "device", "shape", "dev_index", "lstride")
+
+    def __init__(self, x, allow_none=False, levels=False, output=False):
+        self.dev_index, self.lstride = None, None
         if x is None:
             if not allow_none:
                 raise ValueError("missing field argument")
@@ -49,21 +55,43 @@ class _Arg:
         if _is_torch(x):
             import torch
 
-            if x.dtype != torch.float32 or not x.is_contiguous():
-                raise ValueError("device fields must be contiguous float32 tensors")
+            if x.dtype != torch.float32:
+                raise ValueError("device fields must be float32 tensors")
             if not x.is_cuda:
                 raise ValueError("torch tensors must live on the GPU; pass numpy arrays for host memory")
+            if levels and x.dim() == 3 and not x.is_contiguous():
+                nlev, ny, nx = x.shape
+                if x.stride(2) != 1 or x.stride(1) != nx or x.stride(0) < ny * nx or x.stride(0) % 4 != 0:
+                    raise ValueError("a level batch must be (nlev, ny, nx) with contiguous levels and a level stride that is a multiple of 4")
+            elif not x.is_contiguous():
+                raise ValueError("device fields must be contiguous float32 tensors")
             self.addr, self.keep, self.device, self.shape = x.data_ptr(), x, True, tuple(x.shape)
+            self.dev_index = x.device.index
+            if levels and x.dim() == 3:
+                self.lstride = int(x.stride(0)) if x.shape[0] > 1 else int(x.shape[1] * x.shape[2])
         else:
+            if output and not (isinstance(x, np.ndarray) and x.dtype == np.float32 and x.flags["C_CONTIGUOUS"]):
+                raise ValueError("an output array must be a C-contiguous float32 numpy array (or a CUDA tensor)")
             a = np.ascontiguousarray(x, dtype=np.float32)  # forcecast, like py_mi_fieldcalc.cc:40
             self.addr, self.keep, self.device, self.shape = a.ctypes.data, a, False, a.shape
+            if levels and a.ndim == 3:
+                self.lstride = int(a.shape[1] * a.shape[2])
 
 
-def _memkind(args):
-    kinds = {a.device for a in args if a.addr is not None}
+def _memkind(args, ctx_device=None):
+    present = [a for a in args if a.addr is not None]
+    kinds = {a.device for a in present}
     if len(kinds) != 1:
         raise ValueError("all fields of one call must be either numpy (host) or CUDA tensors (device)")
+    if ctx_device is not None:
+        for a in present:
+            if a.device and a.dev_index is not None and a.dev_index != ctx_device:
+                raise ValueError("a tensor lives on cuda:%d but this Context was created on device %d" % (a.dev_index, ctx_device))
     return MEM_DEVICE if kinds.pop() else MEM_HOST
+
+
+def _same_shape(args, shape):
+    return all(a.addr is None or tuple(a.shape) == tuple(shape) for a in args)
 
 
 def _empty_like(ref, shape=None):
@@ -121,7 +149,11 @@ class Context:
     def use_torch_stream(self):
         import torch
 
-        self.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reload_env(self):
+        """Re-read the MIFC_* tuning / diagnostic variables (they are read when a context is created)."""
+        self._lib.mifc_reload_env(self._ctx)
 
     def synchronize(self):
         if not self._lib.mifc_synchronize(self._ctx):
@@ -186,13 +218,20 @@ class Context:
         before the fields, tail: arguments between the outputs and the flag."""
         fa = [_Arg(f, allow_none=True) for f in fields]
         ref = next(f for f in fields if f is not None)
-        nx, ny = self._nxny(_Arg(ref))
+        ra = _Arg(ref)
+        if len(ra.shape) != 2:
+            return None  # like the reference's binding (py_mi_fieldcalc.cc:82-83): not a 2-D field
+        nx, ny = self._nxny(ra)
         outs = list(outs)
         for k in range(n_out):
             if outs[k] is None:
                 outs[k] = _empty_like(ref)
-        oa = [_Arg(o) for o in outs]
-        mk = _memkind(fa + oa)
+        oa = [_Arg(o, output=True) for o in outs]
+        # every field of the call has the shape of the first one; the reference's binding returns None
+        # otherwise (same_dims, py_mi_fieldcalc.cc:82-83) -- here it also keeps the kernels inside the buffers
+        if not _same_shape(fa + oa, ra.shape):
+            return None
+        mk = _memkind(fa + oa, self.device)
         self._bind_stream(mk)
         fd = ctypes.c_int(int(fdefined))
         args = (list(lead) + [nx, ny] + list(pre) + [a.addr for a in fa] + list(scalars) + [a.addr for a in oa] + list(tail)
@@ -406,11 +445,16 @@ class Context:
         ref = fields[0] if len(fields) else out
         if ref is None:
             raise ValueError("no member fields and no output to take the shape from")
-        nx, ny = self._nxny(_Arg(ref))
+        ra = _Arg(ref)
+        if len(ra.shape) != 2:
+            return None
+        nx, ny = self._nxny(ra)
         if out is None:
             out = _empty_like(ref)
-        oa = _Arg(out)
-        mk = _memkind(fa + [oa])
+        oa = _Arg(out, output=True)
+        if not _same_shape(fa + [oa], ra.shape):
+            return None
+        mk = _memkind(fa + [oa], self.device)
         self._bind_stream(mk)
         table = (ctypes.c_void_p * max(len(fa), 1))(*[a.addr for a in fa])
         args = list(lead) + [nx, ny, ctypes.addressof(table)]
@@ -452,8 +496,10 @@ class Context:
             rvort = _empty_like(u)
         if diverg is None and "diverg" in want:
             diverg = _empty_like(u)
-        ar, ad = _Arg(rvort, allow_none=True), _Arg(diverg, allow_none=True)
-        mk = _memkind([au, av, ax, ay, ar, ad])
+        ar, ad = _Arg(rvort, allow_none=True, output=True), _Arg(diverg, allow_none=True, output=True)
+        if not _same_shape([av, ar, ad], au.shape) or not _same_shape([ax, ay], (ny, nx)):
+            raise ValueError("u, v, rvort, diverg must be (nlev, ny, nx) and xmapr, ymapr (ny, nx)")
+        mk = _memkind([au, av, ax, ay, ar, ad], self.device)
         self._bind_stream(mk)
         flags = np.full(nlev, SOME_DEFINED, dtype=np.int32) if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
         rc = self._call(
@@ -480,8 +526,10 @@ class Context:
             out0 = _empty_like(f0)
         if two and out1 is None:
             out1 = _empty_like(f0)
-        o0, o1 = _Arg(out0), _Arg(out1 if two else None, allow_none=True)
-        mk = _memkind([a0, a1, ax, ay, af, o0, o1])
+        o0, o1 = _Arg(out0, output=True), _Arg(out1 if two else None, allow_none=True, output=True)
+        if len(a0.shape) != 3 or not _same_shape([a1, o0, o1], a0.shape) or not _same_shape([ax, ay, af], (ny, nx)):
+            raise ValueError("level fields must be (nlev, ny, nx) and the map / Coriolis fields (ny, nx)")
+        mk = _memkind([a0, a1, ax, ay, af, o0, o1], self.device)
         self._bind_stream(mk)
         flags = np.full(nlev, SOME_DEFINED, dtype=np.int32) if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
         rc = self._call("mifc_stencil_levels", [code, nx, ny, nlev, a0.addr, a1.addr, ax.addr, ay.addr, af.addr, o0.addr, o1.addr,
@@ -493,21 +541,46 @@ class Context:
         return (r0, r1), flags
 
     def vortdiv_levels_enqueue(self, u, v, xmapr, ymapr, rvort, diverg, fdefined=None, undef=UNDEF, n_undefined=None):
-        """Asynchronous form on device tensors; n_undefined: int64 CUDA tensor[nlev] or None."""
-        au, av, ax, ay = _Arg(u), _Arg(v), _Arg(xmapr), _Arg(ymapr)
-        ar, ad = _Arg(rvort, allow_none=True), _Arg(diverg, allow_none=True)
+        """Asynchronous form on device tensors; n_undefined: int64 CUDA tensor[nlev] or None.
+        u, v and rvort, diverg may be level-padded batches (see batch_empty)."""
+        au, av, ax, ay = _Arg(u, levels=True), _Arg(v, levels=True), _Arg(xmapr), _Arg(ymapr)
+        ar, ad = _Arg(rvort, allow_none=True, levels=True), _Arg(diverg, allow_none=True, levels=True)
+        if len(au.shape) != 3:
+            raise ValueError("u, v must have shape (nlev, ny, nx)")
         nlev, ny, nx = au.shape
+        if not _same_shape([av, ar, ad], au.shape) or not _same_shape([ax, ay], (ny, nx)):
+            raise ValueError("u, v, rvort, diverg must be (nlev, ny, nx) and xmapr, ymapr (ny, nx)")
+        if _memkind([au, av, ax, ay, ar, ad], self.device) != MEM_DEVICE:
+            raise ValueError("the *_enqueue calls take device tensors only")
+        outs = [a for a in (ar, ad) if a.addr is not None]
+        if av.lstride != au.lstride or (len(outs) == 2 and outs[0].lstride != outs[1].lstride):
+            raise ValueError("u and v (and rvort and diverg) must share one level stride")
         flags = None if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
         self._bind_stream(MEM_DEVICE)
         rc = self._call(
-            "mifc_vortdiv_levels_enqueue",
+            "mifc_vortdiv_levels_strided_enqueue",
             [
-                nx, ny, nlev, au.addr, av.addr, ax.addr, ay.addr, ar.addr, ad.addr,
+                nx, ny, nlev, au.addr, av.addr, ax.addr, ay.addr, ar.addr, ad.addr, au.lstride, outs[0].lstride,
                 None if flags is None else flags.ctypes.data, float(undef),
                 None if n_undefined is None else n_undefined.data_ptr(),
             ],
         )
         return bool(rc)
+
+    def batch_level_stride(self, nx, ny):
+        """Recommended distance (floats) between the levels of a device-resident batch (mifc_batch_level_stride)."""
+        return int(self._lib.mifc_batch_level_stride(int(nx), int(ny)))
+
+    def batch_empty(self, nlev, ny, nx, level_stride=None):
+        """Uninitialised (nlev, ny, nx) float32 device batch whose levels are level_stride floats apart
+        (default: batch_level_stride).  The padding between levels is never read or written."""
+        import torch
+
+        ls = self.batch_level_stride(nx, ny) if level_stride is None else int(level_stride)
+        if ls < ny * nx or ls % 4 != 0:
+            raise ValueError("level stride must be a multiple of 4 and at least ny*nx")
+        base = torch.empty(nlev * ls, dtype=torch.float32, device=torch.device("cuda", self.device))
+        return torch.as_strided(base, (nlev, ny, nx), (ls, nx, 1))
 
     def hlevel_derived_levels(self, u, v, t, q, ps, alevel, blevel, fdef_wind=None, fdef_thermo=None, undef=UNDEF,
                               want=("ff", "rh", "theta"), out=None):
@@ -521,7 +594,9 @@ class Context:
                 out[k] = _empty_like(ref)
         a = {k: _Arg(x, allow_none=True) for k, x in dict(u=u, v=v, t=t, q=q, ps=ps).items()}
         o = {k: _Arg(out.get(k), allow_none=True) for k in ("ff", "rh", "theta")}
-        mk = _memkind(list(a.values()) + list(o.values()))
+        if not _same_shape([a[k] for k in ("u", "v", "t", "q")] + list(o.values()), (nlev, ny, nx)) or not _same_shape([a["ps"]], (ny, nx)):
+            raise ValueError("level fields must be (nlev, ny, nx) and ps (ny, nx)")
+        mk = _memkind(list(a.values()) + list(o.values()), self.device)
         self._bind_stream(mk)
         al = np.ascontiguousarray(alevel if alevel is not None else np.zeros(nlev), dtype=np.float32).reshape(nlev)
         bl = np.ascontiguousarray(blevel if blevel is not None else np.ones(nlev), dtype=np.float32).reshape(nlev)
@@ -551,6 +626,10 @@ class Context:
         bl = np.ascontiguousarray(blevel, dtype=np.float32).reshape(nlev)
         fw = None if fdef_wind is None else np.array(fdef_wind, np.int32).reshape(nlev).copy()
         ft = None if fdef_thermo is None else np.array(fdef_thermo, np.int32).reshape(nlev).copy()
+        if not _same_shape(a[:4] + o, (nlev, ny, nx)) or not _same_shape([a[4]], (ny, nx)):
+            raise ValueError("level fields must be (nlev, ny, nx) and ps (ny, nx)")
+        if _memkind(a + o, self.device) != MEM_DEVICE:
+            raise ValueError("the *_enqueue calls take device tensors only")
         self._bind_stream(MEM_DEVICE)
         rc = self._call(
             "mifc_hlevel_derived_levels_enqueue",
@@ -560,16 +639,28 @@ class Context:
         return bool(rc)
 
     def vortdiv_slab_enqueue(self, nx, ny_global, j0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, fdefined_in=SOME_DEFINED,
-                             undef=UNDEF, n_undefined=None):
-        """Row-slab form (see include/mifc.h); all tensors on the device."""
+                             undef=UNDEF, n_undefined=None, rows=None, accumulate=False):
+        """Row-slab form (see include/mifc.h); all tensors on the device.  rows=(begin, end) restricts the
+        launch to those owned rows (halo overlap); accumulate=True adds to n_undefined instead of zeroing it."""
         a = [_Arg(x, allow_none=True) for x in (u_halo, v_halo, xmapr, ymapr, rvort, diverg)]
+        if not _same_shape(a[:2], (ny_local + 2, nx)) or not _same_shape(a[2:], (ny_local, nx)):
+            raise ValueError("u_halo, v_halo must be (ny_local + 2, nx); xmapr, ymapr, rvort, diverg (ny_local, nx)")
+        if _memkind(a, self.device) != MEM_DEVICE:
+            raise ValueError("the *_enqueue calls take device tensors only")
         self._bind_stream(MEM_DEVICE)
+        r0, r1 = (0, int(ny_local)) if rows is None else (int(rows[0]), int(rows[1]))
         rc = self._call(
-            "mifc_vortdiv_slab_enqueue",
-            [int(nx), int(ny_global), int(j0), int(ny_local)] + [x.addr for x in a]
-            + [int(fdefined_in), float(undef), None if n_undefined is None else n_undefined.data_ptr()],
+            "mifc_vortdiv_slab_rows_enqueue",
+            [int(nx), int(ny_global), int(j0), int(ny_local), r0, r1] + [x.addr for x in a]
+            + [int(fdefined_in), float(undef), None if n_undefined is None else n_undefined.data_ptr(), 1 if accumulate else 0],
         )
         return bool(rc)
+
+    def halo_copy_enqueue(self, dst, src_ctx, src):
+        """dst (tensor on this context's device) <- src (tensor on src_ctx's device), see mifc_halo_copy_enqueue."""
+        if dst.numel() != src.numel() or not dst.is_contiguous() or not src.is_contiguous():
+            raise ValueError("halo rows must be contiguous and of equal length")
+        return bool(self._call("mifc_halo_copy_enqueue", [dst.data_ptr(), src_ctx._ctx, src.data_ptr(), dst.numel()]))
 
     def diag_division(self, a, b, g, shared, plain):
         """Arithmetic self-check (see include/mifc.h); device tensors of equal length."""

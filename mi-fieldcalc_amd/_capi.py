@@ -37,6 +37,7 @@ SIGNATURES = {
     "mifc_set_stream": ("i", ["ctx", "p"]),
     "mifc_use_own_stream": ("i", ["ctx"]),
     "mifc_synchronize": ("i", ["ctx"]),
+    "mifc_reload_env": ("i", ["ctx"]),
     "mifc_device_alloc": ("p", ["ctx", "z"]),
     "mifc_device_free": ("i", ["ctx", "p"]),
     "mifc_copy_to_device": ("i", ["ctx", "p", "p", "z"]),
@@ -121,6 +122,8 @@ SIGNATURES = {
     "mifc_vortdiv_levels": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_stencil_levels": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_vortdiv_levels_enqueue": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "pu"]),
+    "mifc_batch_level_stride": ("z", ["i", "i"]),
+    "mifc_vortdiv_levels_strided_enqueue": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "z", "z", "pi", "f", "pu"]),
     "mifc_hlevel_derived_levels": (
         "i",
         ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "p", "pi", "pi", "pi", "pi", "pi", "f", "i"],
@@ -130,6 +133,8 @@ SIGNATURES = {
         ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "p", "pi", "pi", "f", "pu"],
     ),
     "mifc_vortdiv_slab_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu"]),
+    "mifc_vortdiv_slab_rows_enqueue": ("i", ["ctx", "i", "i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu", "i"]),
+    "mifc_halo_copy_enqueue": ("i", ["ctx", "p", "ctx", "p", "z"]),
     # diagnostics
     "mifc_bench_stream2": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "z"]),
     "mifc_diag_division": ("i", ["ctx", "p", "p", "p", "p", "p", "z"]),

@@ -104,6 +104,15 @@ bool pinned_release(mifc_ctx* c)
   return true;
 }
 
+bool scratch_release(mifc_ctx* c)
+{
+  hipError_t e = hipEventRecord(c->scratch_read, c->stream);
+  if (e != hipSuccess)
+    return fail(c, "hipEventRecord", e);
+  c->scratch_read_pending = true;
+  return true;
+}
+
 u64* pinned_counts(mifc_ctx* c)
 {
   return reinterpret_cast<u64*>(c->h_pinned);
@@ -240,8 +249,7 @@ u64 stencil_denominator(int op, int nx, int ny)
 
 bool host_pipeline_enabled()
 {
-  const char* e = std::getenv("MIFC_HOST_PIPELINE"); // "0": stage whole batches (for A/B measurements)
-  return !(e && e[0] == '0');
+  return mifc::env().host_pipeline; // MIFC_HOST_PIPELINE=0: stage whole batches (for A/B measurements)
 }
 
 int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, float undef, int memkind)
@@ -394,12 +402,24 @@ mifc_ctx* mifc_create(int device)
     return nullptr;
   }
   c->stream = c->own_stream;
-  if (hipEventCreateWithFlags(&c->pinned_read, hipEventDisableTiming) != hipSuccess) {
+  if (hipEventCreateWithFlags(&c->pinned_read, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->scratch_read, hipEventDisableTiming) != hipSuccess) {
+    if (c->pinned_read)
+      (void)hipEventDestroy(c->pinned_read);
     (void)hipStreamDestroy(c->own_stream);
     delete c;
     return nullptr;
   }
+  mifc::env_reload(); // the tuning / diagnostic environment is read here, never on a launch path
   return c;
+}
+
+int mifc_reload_env(mifc_ctx* c)
+{
+  if (!c)
+    return 0;
+  mifc::env_reload();
+  return 1;
 }
 
 void mifc_destroy(mifc_ctx* c)
@@ -421,6 +441,8 @@ void mifc_destroy(mifc_ctx* c)
     (void)hipHostFree(c->h_pinned);
   if (c->pinned_read)
     (void)hipEventDestroy(c->pinned_read);
+  if (c->scratch_read)
+    (void)hipEventDestroy(c->scratch_read);
   for (hipEvent_t e : c->tev)
     if (e)
       (void)hipEventDestroy(e);
@@ -437,21 +459,33 @@ const char* mifc_last_error(const mifc_ctx* c)
   return c ? c->err.c_str() : "no context (no usable HIP device)";
 }
 
+// Work already queued on the old stream may still read the context's device scratch (per-level
+// flags, hybrid coefficients of an *_enqueue call): the new stream waits for it before anything
+// issued there can rewrite that scratch.
+static int switch_stream(mifc_ctx* c, hipStream_t s)
+{
+  if (s == c->stream)
+    return 1;
+  if (c->scratch_read_pending)
+    MIFC_HIP(c, hipStreamWaitEvent(s, c->scratch_read, 0));
+  c->stream = s;
+  return 1;
+}
+
 int mifc_set_stream(mifc_ctx* c, void* hip_stream)
 {
   if (!c)
     return 0;
   enter(c);
-  c->stream = static_cast<hipStream_t>(hip_stream); // null = HIP's default stream
-  return 1;
+  return switch_stream(c, static_cast<hipStream_t>(hip_stream)); // null = HIP's default stream
 }
 
 int mifc_use_own_stream(mifc_ctx* c)
 {
   if (!c)
     return 0;
-  c->stream = c->own_stream;
-  return 1;
+  enter(c);
+  return switch_stream(c, c->own_stream);
 }
 
 int mifc_synchronize(mifc_ctx* c)
@@ -1009,8 +1043,7 @@ static int run_fused2(mifc_ctx* c, mifc::Fused2Params& P, int* fdefined)
 
 static bool fused2_enabled()
 {
-  const char* e = std::getenv("MIFC_FUSED2"); // "0": always the multi-pass path (A/B measurements, tests)
-  return !(e && e[0] == '0');
+  return mifc::env().fused2; // MIFC_FUSED2=0: always the multi-pass path (A/B measurements, tests)
 }
 
 // thermalFrontParameter, FieldCalculations.cc:2266-2309.  One fused launch where
@@ -1180,11 +1213,30 @@ int mifc_stencil_levels(mifc_ctx* c, int op, int nx, int ny, int nlev, const flo
 int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
                                 float* rvort, float* diverg, const int* fdefined_in, float undef, unsigned long long* n_undefined_dev)
 {
+  const size_t n = (size_t)(nx > 0 ? nx : 0) * (size_t)(ny > 0 ? ny : 0);
+  return mifc_vortdiv_levels_strided_enqueue(c, nx, ny, nlev, u, v, xmapr, ymapr, rvort, diverg, n, n, fdefined_in, undef, n_undefined_dev);
+}
+
+size_t mifc_batch_level_stride(int nx, int ny)
+{
+  if (nx <= 0 || ny <= 0)
+    return 0;
+  return mifc::padded_level_stride((size_t)nx * (size_t)ny);
+}
+
+int mifc_vortdiv_levels_strided_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
+                                        float* rvort, float* diverg, size_t in_level_stride, size_t out_level_stride, const int* fdefined_in,
+                                        float undef, unsigned long long* n_undefined_dev)
+{
   if (!c || (!rvort && !diverg))
     return 0;
   enter(c);
   if (nx < 3 || ny < 3 || nlev < 1)
     return 0;
+  if (in_level_stride < (size_t)nx * ny || out_level_stride < (size_t)nx * ny) {
+    c->err = "mifc_vortdiv_levels_strided_enqueue: a level stride is smaller than one field";
+    return 0;
+  }
   if (!ensure_levels(c, (size_t)nlev))
     return 0;
   mifc::StencilParams P;
@@ -1208,8 +1260,8 @@ int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const flo
   P.f1 = v;
   P.xmapr = xmapr;
   P.ymapr = ymapr;
-  P.in_level_stride = (long)nx * ny;
-  P.out_level_stride = (long)nx * ny;
+  P.in_level_stride = (long)in_level_stride;
+  P.out_level_stride = (long)out_level_stride;
   P.undef = undef;
   if (!pinned_acquire(c))
     return 0;
@@ -1234,6 +1286,8 @@ int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const flo
   if (n_undefined_dev)
     MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64) * (size_t)nlev, c->stream));
   MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
+  if (!every_all && !scratch_release(c)) // the kernel reads c->d_flags
+    return 0;
   return 1;
 }
 
@@ -1308,8 +1362,11 @@ static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u,
   MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 3 * sizeof(u64) * (size_t)nlev, c->stream));
   if (prepared_only) // the caller launches chunk by chunk (host pipeline)
     *prepared_only = P;
-  else
+  else {
     MIFC_LAUNCH(c, mifc::launch_derived_levels(P, c->stream));
+    if (!P.n_inline && !scratch_release(c)) // the kernel reads c->d_flags and c->d_ab
+      return 0;
+  }
   if (every_all_out)
     *every_all_out = every_all;
   return 1;
@@ -1441,6 +1498,14 @@ int mifc_hlevel_derived_levels(mifc_ctx* c, int nx, int ny, int nlev, const floa
 int mifc_vortdiv_slab_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny_local, const float* u_halo, const float* v_halo, const float* xmapr,
                               const float* ymapr, float* rvort, float* diverg, int fdefined_in, float undef, unsigned long long* n_undefined_dev)
 {
+  return mifc_vortdiv_slab_rows_enqueue(c, nx, ny_global, j0, ny_local, 0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, fdefined_in, undef,
+                                        n_undefined_dev, 0);
+}
+
+int mifc_vortdiv_slab_rows_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny_local, int row_begin, int row_end, const float* u_halo,
+                                   const float* v_halo, const float* xmapr, const float* ymapr, float* rvort, float* diverg, int fdefined_in,
+                                   float undef, unsigned long long* n_undefined_dev, int accumulate_count)
+{
   if (!c || (!rvort && !diverg))
     return 0;
   enter(c);
@@ -1449,6 +1514,13 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny
   // a slab that owns a global edge row must also own the row it is filled from
   if ((j0 == 0 || j0 + ny_local == ny_global) && ny_local < 2)
     return 0;
+  if (row_begin < 0 || row_end > ny_local || row_begin >= row_end)
+    return 0;
+  // ... and a row range must keep the two together (fillEdges copies row 1 to row 0, row ny-2 to row ny-1)
+  if ((j0 == 0 && (row_begin == 1 || row_end == 1)) || (j0 + ny_local == ny_global && (row_begin == ny_local - 1 || row_end == ny_local - 1))) {
+    c->err = "mifc_vortdiv_slab_rows_enqueue: a row range must not separate a global edge row from the row it is filled from";
+    return 0;
+  }
   mifc::StencilParams P;
   std::memset(&P, 0, sizeof P);
   P.op = mifc::ST_VORTDIV;
@@ -1474,13 +1546,46 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny
   P.every_level_all_defined = (fdefined_in == MIFC_ALL_DEFINED) ? 1 : 0;
   P.all_defined = nullptr;
   P.n_undefined = n_undefined_dev;
+  if (row_begin != 0 || row_end != ny_local) {
+    P.row_begin = row_begin;
+    P.row_end = row_end;
+  }
   if (!P.every_level_all_defined && !n_undefined_dev) {
     c->err = "mifc_vortdiv_slab_enqueue: n_undefined_dev is required unless the input is ALL_DEFINED";
     return 0;
   }
-  if (n_undefined_dev)
+  if (n_undefined_dev && !accumulate_count)
     MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64), c->stream));
   MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
+  return 1;
+}
+
+int mifc_halo_copy_enqueue(mifc_ctx* dst_ctx, float* dst_dev, mifc_ctx* src_ctx, const float* src_dev, size_t n_floats)
+{
+  if (!dst_ctx || !src_ctx || !dst_dev || !src_dev)
+    return 0;
+  enter(src_ctx);
+  if (n_floats == 0)
+    return 1;
+  // the rows must have been produced: order the copy after what is queued on the source context's stream
+  if (src_ctx != dst_ctx || src_ctx->stream != dst_ctx->stream) {
+    hipEvent_t ready = nullptr;
+    MIFC_HIP(src_ctx, hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ready, src_ctx->stream);
+    enter(dst_ctx);
+    if (e == hipSuccess)
+      e = hipStreamWaitEvent(dst_ctx->stream, ready, 0);
+    (void)hipEventDestroy(ready); // released once the wait has consumed it
+    if (e != hipSuccess) {
+      fail(dst_ctx, "halo copy: event", e);
+      return 0;
+    }
+  }
+  enter(dst_ctx);
+  if (src_ctx->device == dst_ctx->device)
+    MIFC_HIP(dst_ctx, hipMemcpyAsync(dst_dev, src_dev, n_floats * sizeof(float), hipMemcpyDeviceToDevice, dst_ctx->stream));
+  else
+    MIFC_HIP(dst_ctx, hipMemcpyPeerAsync(dst_dev, dst_ctx->device, src_dev, src_ctx->device, n_floats * sizeof(float), dst_ctx->stream));
   return 1;
 }
 

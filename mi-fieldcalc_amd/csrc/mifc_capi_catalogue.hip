@@ -592,9 +592,9 @@ int mifc_shapiro2_filter(mifc_ctx* c, int nx, int ny, const float* field, float*
   {
     // the four sweeps in one launch; it needs source and destination to be different arrays, so an
     // in-place call goes through the scratch field and is copied back
-    const char* e = std::getenv("MIFC_SHAPIRO_FUSED"); // "0": the four-launch path (A/B measurements, tests)
+    // MIFC_SHAPIRO_FUSED=0: the four-launch path (A/B measurements, tests)
     float* d_dst = (d_out != d_in) ? d_out : static_cast<float*>(c->slot[8]);
-    if (!(e && e[0] == '0') && mifc::shapiro2_fused_supported(nx, ny, d_in, d_dst)) {
+    if (mifc::env().shapiro_fused && mifc::shapiro2_fused_supported(nx, ny, d_in, d_dst)) {
       MIFC_LAUNCH(c, mifc::launch_shapiro2_fused(nx, ny, all ? 1 : 0, undef, d_in, d_dst, c->stream));
       if (d_dst != d_out)
         MIFC_HIP(c, hipMemcpyAsync(d_out, d_dst, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));

@@ -35,6 +35,11 @@ struct mifc_ctx
   // variants); waited on before the mirror is rewritten
   hipEvent_t pinned_read = nullptr;
   bool pinned_read_pending = false;
+  // recorded after every asynchronous launch that READS the context-owned device scratch
+  // (d_flags, d_ab): a switch to another stream makes that stream wait on it before the scratch
+  // can be rewritten there (the *_enqueue entry points never synchronise)
+  hipEvent_t scratch_read = nullptr;
+  bool scratch_read_pending = false;
   // chunked, full-duplex streaming of host-resident level batches (created on first use)
   mifc::HostPipe* pipe = nullptr;
   // host fields the caller declared constant (mifc_hold_field): device copies that stage_in reuses
@@ -93,6 +98,7 @@ bool ensure_slot(mifc_ctx* c, int s, size_t bytes);
 bool ensure_levels(mifc_ctx* c, size_t nlev);
 bool pinned_acquire(mifc_ctx* c);
 bool pinned_release(mifc_ctx* c);
+bool scratch_release(mifc_ctx* c);
 u64* pinned_counts(mifc_ctx* c);
 unsigned char* pinned_flags(mifc_ctx* c);
 float* pinned_ab(mifc_ctx* c);

@@ -1,0 +1,34 @@
+// mifc_env.h -- the tuning / diagnostic environment variables of the library,
+// read ONCE (mifc_create, mifc_reload_env) into a process-wide snapshot.  No
+// launch path calls getenv: the launchers read this struct.  The variables
+// select between code paths that all give the reference's results (A/B
+// measurements, tests of every fallback); none of them changes what is computed.
+#ifndef MIFC_ENV_H
+#define MIFC_ENV_H
+
+namespace mifc {
+
+struct Env
+{
+  bool force_cell_kernel = false; // MIFC_FORCE_CELL_KERNEL: one-lane-per-cell stencil kernels everywhere
+  bool host_pipeline = true;      // MIFC_HOST_PIPELINE=0: stage host-resident level batches whole
+  bool fused2 = true;             // MIFC_FUSED2=0: multi-pass thermalFrontParameter / plevelqvector
+  bool shapiro_fused = true;      // MIFC_SHAPIRO_FUSED=0: four-launch shapiro2_filter
+  int ewise_max_blocks = 0;       // MIFC_EWISE_MAX_BLOCKS (> 0 overrides the grid cap of the table kernels)
+  int scalar_rows_r = -1;         // MIFC_SCALAR_ROWS_R: -1 unset, 0 = "set, keep the default height", > 0 band height
+  int fused2_band = 0;            // MIFC_FUSED2_BAND (> 0 overrides the band height of the fused two-stage kernels)
+  int host_threads = 0;           // MIFC_HOST_THREADS (> 0)
+  int host_chunk_mib = 0;         // MIFC_HOST_CHUNK_MIB (> 0)
+  int derived_blocks = 0;         // MIFC_DERIVED_BLOCKS (> 0 overrides the persistent grid of the fused derived kernel)
+  bool has_vortdiv_tune = false;  // MIFC_VORTDIV_TUNE="R=8,D=1,..."
+  char vortdiv_tune[256] = {0};
+};
+
+// the current snapshot (defaults until the first reload)
+const Env& env();
+// re-reads the process environment into the snapshot
+void env_reload();
+
+} // namespace mifc
+
+#endif // MIFC_ENV_H

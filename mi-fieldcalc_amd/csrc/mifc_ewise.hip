@@ -268,9 +268,8 @@ hipError_t launch_ewise_op(const EwiseParams& prm, hipStream_t stream)
     // (MIFC_EWISE_MAX_BLOCKS overrides the cap, for A/B measurements).
     const bool tables = ewise_needs_ewt(prm) || ewise_needs_pow(prm);
     int cap = tables ? 256 * 16 : 0x7fffffff;
-    if (const char* e = std::getenv("MIFC_EWISE_MAX_BLOCKS"))
-      if (std::atoi(e) > 0)
-        cap = std::atoi(e);
+    if (env().ewise_max_blocks > 0)
+      cap = env().ewise_max_blocks;
     hipLaunchKernelGGL((ewise_kernel<OP, true>), dim3(grid_for(n4, block, cap)), dim3(block), 0, stream, prm);
     const int tail = prm.n - n4 * 4;
     if (tail > 0) {

@@ -518,9 +518,8 @@ hipError_t launch(const Fused2Params& p, hipStream_t stream)
     band = 4;
   if (band > 64)
     band = 64;
-  if (const char* e = std::getenv("MIFC_FUSED2_BAND")) // A/B measurements
-    if (std::atoi(e) > 0)
-      band = std::atoi(e);
+  if (env().fused2_band > 0) // A/B measurements
+    band = env().fused2_band;
   const int nbands = (interior + band - 1) / band;
   const int n_main = nbands * ntiles;
   int n_edge = 0; // TFP with an ALL_DEFINED input counts its edge cells in the tiles (nothing wrapped is tested)

@@ -1,5 +1,6 @@
 // mifc_hostpipe.hip -- see mifc_hostpipe.h.
 #include "mifc_hostpipe.h"
+#include "mifc_env.h"
 
 #include <atomic>
 #include <condition_variable>
@@ -98,8 +99,8 @@ int copy_threads()
   // two per direction keep ahead of the link (profiles/r01/hostpath_probe.txt: 29 GB/s per
   // thread); more did not help in the sweep (profiles/r01/hostpipe_sweep.txt)
   int n = 4;
-  if (const char* e = std::getenv("MIFC_HOST_THREADS"))
-    n = std::atoi(e);
+  if (env().host_threads > 0)
+    n = env().host_threads;
   const int hw = (int)std::thread::hardware_concurrency();
   if (hw > 0 && n > hw)
     n = hw;
@@ -182,9 +183,8 @@ int hostpipe_chunk_levels(size_t n, int nlev)
   if (field_bytes == 0 || (size_t)nlev * field_bytes < (size_t(64) << 20))
     return 0; // under 64 MiB per field the ramp-up costs more than the overlap gains
   size_t chunk_mib = 32; // per field and chunk
-  if (const char* e = std::getenv("MIFC_HOST_CHUNK_MIB"))
-    if (std::atoi(e) > 0)
-      chunk_mib = (size_t)std::atoi(e);
+  if (env().host_chunk_mib > 0)
+    chunk_mib = (size_t)env().host_chunk_mib;
   size_t lev = (chunk_mib << 20) / field_bytes;
   if (lev < 1)
     lev = 1;

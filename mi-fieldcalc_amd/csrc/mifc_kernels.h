@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "mifc_env.h"
+
 namespace mifc {
 
 typedef unsigned long long u64;
@@ -61,6 +63,9 @@ struct EwiseParams
 };
 
 hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream);
+
+// recommended distance (in floats) between the levels of a device-resident batch of fields of n cells
+size_t padded_level_stride(size_t n);
 
 // Fused (ff, rh, theta) over levels, BASELINE.json config 2.
 struct DerivedParams
@@ -224,6 +229,11 @@ struct StencilParams
   int every_level_all_defined;
   float undef;
   u64* n_undefined; // device u64[nlev]
+  // row slabs of the wind operators only: restrict the launch to the owned output rows
+  // [row_begin, row_end) (0, 0 = all).  Lets a caller compute the rows that need no halo while
+  // the halo exchange is in flight.  A range must not separate a global edge row from the row
+  // it is filled from (rows 0 / 1 and ny-2 / ny-1 of the whole field stay together).
+  int row_begin, row_end;
 };
 
 hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream);

@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256) void stencil_cell_kernel(const StencilParams P
   const int jmax = P.ny_global - 2; // last computed global row
   unsigned int bad = 0;
 
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_local; i += (long)gridDim.x * blockDim.x) {
+  const long cell_begin = (P.row_end > P.row_begin) ? (long)P.row_begin * nx : 0;
+  const long cell_end = (P.row_end > P.row_begin) ? (long)P.row_end * nx : n_local;
+  for (long i = cell_begin + (long)blockIdx.x * blockDim.x + threadIdx.x; i < cell_end; i += (long)gridDim.x * blockDim.x) {
     const int jl = (int)(i / nx);
     const int c = (int)(i - (long)jl * nx);
     const int j = P.j0 + jl;
@@ -279,7 +281,7 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
     if (handled)
       return e;
   }
-  if (prm.op == ST_ADVECTION && !std::getenv("MIFC_FORCE_CELL_KERNEL")) {
+  if (prm.op == ST_ADVECTION && !env().force_cell_kernel) {
     bool handled = false;
     const hipError_t e = launch_advection_oneshot(prm, stream, &handled);
     if (handled)

@@ -447,7 +447,7 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
     return hipSuccess;
   if (prm.in_level_stride % 4 != 0 || prm.out_level_stride % 4 != 0)
     return hipSuccess;
-  if (std::getenv("MIFC_FORCE_CELL_KERNEL"))
+  if (env().force_cell_kernel)
     return hipSuccess;
 
   SRowsParams rp;
@@ -462,11 +462,12 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   // 8-row bands; a small launch (the reference's single-field call: one level) is latency-bound and
   // gets shorter ones -- more waves on the chip, the halo re-reads stay in L2
   rp.R = 8;
-  if (!std::getenv("MIFC_SCALAR_ROWS_R")) {
+  const int forced_r = env().scalar_rows_r; // -1: not set
+  if (forced_r < 0) {
     while (rp.R > 2 && (long)prm.nlev * ((ny - 2 + rp.R - 1) / rp.R) * rp.nwc < 2048) // waves of the launch
       rp.R /= 2;
-  } else if (std::atoi(std::getenv("MIFC_SCALAR_ROWS_R")) > 0) {
-    rp.R = std::atoi(std::getenv("MIFC_SCALAR_ROWS_R")); // A/B measurements
+  } else if (forced_r > 0) {
+    rp.R = forced_r; // A/B measurements
     if (rp.R > 8)
       rp.R = 8;
   }
@@ -498,7 +499,7 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   // a small launch (fewer than 2048 waves even with 8-row bands) takes the one-shot form, and so do one or
   // two levels of any size: their row-walking workgroups would be single waves holding a 48-KiB tile of map
   // factors, three to a CU
-  if (!std::getenv("MIFC_SCALAR_ROWS_R") && ((long)prm.nlev * ((ny - 2 + 7) / 8) * rp.nwc < 2048 || prm.nlev <= 2)) {
+  if (forced_r < 0 && ((long)prm.nlev * ((ny - 2 + 7) / 8) * rp.nwc < 2048 || prm.nlev <= 2)) {
     rp.uB = (ny - 2 + 3) / 4;
     rp.uW = (nx + 255) / 256;
     const long units = (long)prm.nlev * rp.uB * rp.uW;

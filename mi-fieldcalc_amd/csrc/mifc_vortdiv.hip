@@ -70,9 +70,14 @@ struct RowsParams
   int xcd_remap;       // 1: sequence = (b % 8) * per_xcd + b / 8
   int zigzag;          // 1: odd bands walk upwards
   int nt_interior;     // 1: rows no other band touches are loaded nontemporally
-  int exp_nohalo;      // MEASUREMENT ONLY (wrong results): halo rows are not fetched, to price their traffic
-  int exp_nostore;     // MEASUREMENT ONLY: 1 = only lane-0-of-wave-0-like sliver of the stores is issued (read side alone)
-  int exp_noload;      // MEASUREMENT ONLY (wrong results): the field rows are not loaded at all (write side alone)
+  int lgroup;          // one-shot forms: > 0 = consecutive units are the SAME tile on `lgroup` consecutive levels
+                       // (the tile's map factors then come from L2); 0 = address order
+#ifdef MIFC_MEASUREMENT_BUILD // libmifc_measure.so only (tools/): knobs that give wrong results by design
+  int exp_nohalo;      // halo rows are not fetched, to price their traffic
+  int exp_nostore;     // 1 = only a sliver of the stores is issued (read side alone)
+  int exp_noload;      // the field rows are not loaded at all (write side alone)
+  int exp_store_aux;   // != 0: results leave through buffer stores with this cache policy (2 nt, 16 sc1, 17 sc0 sc1, 18 nt sc1)
+#endif
   long idx_lo, idx_hi; // valid flat element range relative to owned row 0 (for clamped scalar loads)
   const float *u, *v, *xm, *ym;
   const float* fc; // coriolis parameter, absvort only
@@ -114,6 +119,46 @@ __device__ __forceinline__ void store4(float* p, const v4f& v)
     *reinterpret_cast<v4f*>(p) = v;
 }
 
+#ifdef MIFC_MEASUREMENT_BUILD
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+// base: wave-uniform start of the level's output field; off: element offset
+__device__ __forceinline__ void store4_policy(int aux, float* base, long off, int n_bytes, const v4f& v)
+{
+  const unsigned long long a = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  void* b = (void*)(((unsigned long long)hi << 32) | lo);
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(b, 0, n_bytes, 0x00020000);
+  const v4u d = __builtin_bit_cast(v4u, v);
+  const int o = (int)(off * 4);
+  switch (aux) {
+  case 2:
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, o, 0, 2);
+    break;
+  case 16:
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, o, 0, 16);
+    break;
+  case 17:
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, o, 0, 17);
+    break;
+  case 18:
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, o, 0, 18);
+    break;
+  default:
+    __builtin_amdgcn_raw_buffer_store_b128(d, rs, o, 0, 0);
+    break;
+  }
+}
+#define MIFC_STORE4(NT_, base_, off_, v_)                                                        \
+  do {                                                                                           \
+    if (P.exp_store_aux)                                                                         \
+      store4_policy(P.exp_store_aux, (base_), (off_), (int)((long)P.ny_local * P.nx * 4), (v_)); \
+    else                                                                                         \
+      store4<NT_>((base_) + (off_), (v_));                                                       \
+  } while (0)
+#else
+#define MIFC_STORE4(NT_, base_, off_, v_) store4<NT_>((base_) + (off_), (v_))
+#endif
+
 __device__ __forceinline__ v4f load4(const float* p)
 {
   return *reinterpret_cast<const v4f*>(p);
@@ -149,6 +194,30 @@ __device__ __forceinline__ void decode_block(const RowsParams& P, int seq, int& 
       b = t - w * P.uB;
     }
   }
+}
+
+// one-shot forms: sequence number -> (level, row block, column segment)
+__device__ __forceinline__ void decode_oneshot(const RowsParams& P, int seq, int& lev, int& rblock, int& wc)
+{
+  const int per_level = P.uB * P.uW;
+  if (P.lgroup > 0) {
+    // groups of `lgroup` levels; inside a group the tile index is slow and the level fast
+    const int per_group = P.lgroup * per_level;
+    const int g = seq / per_group;
+    const int r2 = seq - g * per_group;
+    const int first = g * P.lgroup;
+    const int ng = (P.nlev - first < P.lgroup) ? (P.nlev - first) : P.lgroup; // the last group may be short
+    const int tile = r2 / ng;
+    lev = first + (r2 - tile * ng);
+    rblock = tile / P.uW;
+    wc = tile - rblock * P.uW;
+    return;
+  }
+  // address order: column segment fastest, then row block, then level
+  lev = seq / per_level;
+  const int rem = seq - lev * per_level;
+  rblock = rem / P.uW;
+  wc = rem - rblock * P.uW;
 }
 
 // JAC: the same data pattern (W/E/N/S neighbours of two fields) computes jacobian(field1, field2)
@@ -214,12 +283,15 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
   // step t in [-1, nr] of the walk -> local row; steps past the far halo are clamped to it
   auto load_row = [&](int t) -> RowRegs<V> {
     int tc = t > nr ? nr : t;
+#ifdef MIFC_MEASUREMENT_BUILD
     if (P.exp_nohalo)
       tc = tc < 0 ? 0 : (tc > nr - 1 ? nr - 1 : tc);
+#endif
     const int rowl = up ? (nr - 1 - tc) : tc;
     const long base = (long)(jb + rowl) * nx;
     const bool stream_row = P.nt_interior && tc >= 1 && tc <= nr - 2;
     RowRegs<V> r;
+#ifdef MIFC_MEASUREMENT_BUILD
     if (P.exp_noload) { // write side alone: compute on something that costs no memory traffic
 #pragma unroll
       for (int q = 0; q < V; ++q) {
@@ -232,6 +304,7 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
       r.ev = 0.f;
       return r;
     }
+#endif
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       if (stream_row) { // interior row of the band: read once by this wave only
@@ -242,17 +315,12 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
         r.v[q] = load4(v + base + colq_c[q]);
       }
     }
-#ifdef MIFC_EXPERIMENT_NO_EDGE
-    r.eu = 0.f; // timing experiment only: wrong at wave-column boundaries
-    r.ev = 0.f;
-#else
     // x-neighbour scalar of the wave-column edge.  Only centre rows use it; the
     // clamp keeps the address inside the buffer for the rows that do not.
     long e = base + edge_col;
     e = e < P.idx_lo ? P.idx_lo : (e > P.idx_hi ? P.idx_hi : e);
     r.eu = u[e];
     r.ev = v[e];
-#endif
     return r;
   };
   // ---- prologue: rows -1 .. D into ring slots (rho + 2) % W; issued before the
@@ -377,7 +445,11 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
           zv[3] = zv[2];
           zd[3] = zd[2];
         }
+#ifdef MIFC_MEASUREMENT_BUILD
         if (actq[q] && !(P.exp_nostore && zv[0] != 12345.678f)) {
+#else
+        if (actq[q]) {
+#endif
           const long o = (long)jl * nx + colq[q];
           if (WANT_V) {
             v4f z4;
@@ -385,11 +457,11 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
             z4.y = zv[1];
             z4.z = zv[2];
             z4.w = zv[3];
-            store4<NT>(rv + o, z4);
+            MIFC_STORE4(NT, rv, o, z4);
             if (j == 1 && owns_top_edge) // row part of fillEdges (:70-73)
-              store4<NT>(rv + o - nx, z4);
+              MIFC_STORE4(NT, rv, o - nx, z4);
             if (j == P.nyg - 2 && owns_bottom_edge)
-              store4<NT>(rv + o + nx, z4);
+              MIFC_STORE4(NT, rv, o + nx, z4);
           }
           if (WANT_D) {
             v4f d4;
@@ -397,11 +469,11 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
             d4.y = zd[1];
             d4.z = zd[2];
             d4.w = zd[3];
-            store4<NT>(dv + o, d4);
+            MIFC_STORE4(NT, dv, o, d4);
             if (j == 1 && owns_top_edge)
-              store4<NT>(dv + o - nx, d4);
+              MIFC_STORE4(NT, dv, o - nx, d4);
             if (j == P.nyg - 2 && owns_bottom_edge)
-              store4<NT>(dv + o + nx, d4);
+              MIFC_STORE4(NT, dv, o + nx, d4);
           }
         }
       }
@@ -431,12 +503,8 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
   const int seq = P.xcd_remap ? ((bid & 7) * P.per_xcd + (bid >> 3)) : bid;
   if (seq >= P.n_logical)
     return;
-  // address order: column segment fastest, then row block, then level
-  const int per_level = P.uB * P.uW;
-  const int lev = seq / per_level;
-  const int rem = seq - lev * per_level;
-  const int rblock = rem / P.uW;
-  const int wc = rem - rblock * P.uW;
+  int lev, rblock, wc;
+  decode_oneshot(P, seq, lev, rblock, wc);
 
   const int nx = P.nx;
   const int jl = P.lo + rblock * 4 + wave; // local row of this wave
@@ -564,12 +632,8 @@ __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsP
   const int seq = P.xcd_remap ? ((bid & 7) * P.per_xcd + (bid >> 3)) : bid;
   if (seq >= P.n_logical)
     return;
-  // address order: column segment fastest, then row block, then level
-  const int per_level = P.uB * P.uW;
-  const int lev = seq / per_level;
-  const int rem = seq - lev * per_level;
-  const int rblock = rem / P.uW;
-  const int wc = rem - rblock * P.uW;
+  int lev, rblock, wc;
+  decode_oneshot(P, seq, lev, rblock, wc);
 
   const int nx = P.nx;
   // wave 0 and wave RB+1 hold the halo rows; rows past the computed range are only loaded (clamped to the
@@ -694,11 +758,14 @@ struct Tuning
   int WPB;   // waves per workgroup: 4, 8 or 16 (levels side by side)
   int ZZ;    // odd bands walk upwards (halo rows meet in L2)
   int NTI;   // nontemporal loads for the rows of a band that no other band reads
-  int XH;    // measurement only: skip the halo rows (results are wrong), never set by the library itself
-  int XS;    // measurement only: skip (practically all) stores
-  int PADROWS; // measurement only: the last PADROWS rows of every level are padding (changes the level stride)
-  int XL;      // measurement only: skip the field loads (write side alone)
+  int XH;    // measurement build only: skip the halo rows (results are wrong)
+  int XS;    // measurement build only: skip (practically all) stores
+  int PADROWS; // measurement build only: the last PADROWS rows of every level are padding (changes the level stride)
+  int XL;      // measurement build only: skip the field loads (write side alone)
   int LDSX;    // extra KiB of LDS requested per workgroup: limits the workgroups resident on a CU (occupancy experiments)
+  int STA;     // measurement build only: buffer stores with this cache policy (aux bits)
+  int LG;      // one-shot forms: level-minor unit order in groups of LG levels (0: address order)
+  int RB;      // one-shot tile form: rows per tile (8 or 14)
 };
 
 int tune_value(const char* s, const char* key, int dflt)
@@ -717,9 +784,10 @@ int tune_value(const char* s, const char* key, int dflt)
 
 Tuning current_tuning(int nx)
 {
-  Tuning t = {0, 8, 1, 1, 2, 1, 1, 8, 1, 0, 0, 0, 0, 0, 0}; // R = 6 / WPB = 4 run within 1 % of this but fetch more (halo rows, map factors): HBM traffic 1.13-1.14x vs 1.08x of the minimum
+  Tuning t = {0, 8, 1, 1, 2, 1, 1, 8, 1, 0, 0, 0, 0, 0, 0, 0, 0, 8}; // R = 6 / WPB = 4 run within 1 % of this but fetch more (halo rows, map factors): HBM traffic 1.13-1.14x vs 1.08x of the minimum
   // MIFC_VORTDIV_TUNE="R=8,D=1,NT=1,V=2,ORDER=1,XCD=1,WPB=8" -- used by the sweep tool and the tests
-  if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
+  if (env().has_vortdiv_tune) {
+    const char* s = env().vortdiv_tune;
     t.K = tune_value(s, "K", t.K);
     t.R = tune_value(s, "R", t.R);
     t.D = tune_value(s, "D", t.D);
@@ -731,14 +799,17 @@ Tuning current_tuning(int nx)
     t.ZZ = tune_value(s, "ZZ", t.ZZ);
     t.NTI = tune_value(s, "NTI", t.NTI);
     t.LDSX = tune_value(s, "LDSX", t.LDSX);
-    // knobs that make the kernel compute something else (wrong results by design) are only
-    // honoured when the measurement tools say so explicitly
-    if (std::getenv("MIFC_MEASUREMENT_KNOBS")) {
-      t.XH = tune_value(s, "XH", 0);
-      t.XS = tune_value(s, "XS", 0);
-      t.PADROWS = tune_value(s, "PADROWS", 0);
-      t.XL = tune_value(s, "XL", 0);
-    }
+    t.LG = tune_value(s, "LG", t.LG);
+    t.RB = tune_value(s, "RB", t.RB);
+#ifdef MIFC_MEASUREMENT_BUILD
+    // knobs that make the kernel compute something else (wrong results by design): they exist in
+    // libmifc_measure.so only, which tools/ load explicitly; the product library has no such code
+    t.XH = tune_value(s, "XH", 0);
+    t.XS = tune_value(s, "XS", 0);
+    t.PADROWS = tune_value(s, "PADROWS", 0);
+    t.XL = tune_value(s, "XL", 0);
+    t.STA = tune_value(s, "STA", 0);
+#endif
   }
   if (t.WPB != 1 && t.WPB != 2 && t.WPB != 4 && t.WPB != 8)
     t.WPB = 4; // the kernel is compiled for workgroups of up to 8 waves
@@ -748,7 +819,7 @@ Tuning current_tuning(int nx)
     t.V = 1; // a second 256-column segment would be empty
   if (t.R < 1)
     t.R = 1;
-  const int rmax = 20 / t.V; // map-factor tile in LDS: up to 3*V KiB per row (absvort), 64 KiB at most
+  const int rmax = 32 / t.V; // map-factor tile in LDS: up to 3*V KiB per row (absvort), 96 KiB at most
   if (t.R > rmax)
     t.R = rmax;
   if (t.D < 0)
@@ -817,6 +888,15 @@ inline bool aligned16(const void* p)
 
 } // namespace
 
+// Distance between the levels of a device-resident batch.  The waves of a workgroup walk eight
+// consecutive levels side by side; where those eight streams land in the memory channels depends on
+// the level stride.  (Measured: profiles/r02/placement_sweep.txt.)
+size_t padded_level_stride(size_t n)
+{
+  const size_t n4 = (n + 3) & ~size_t(3);
+  return n4;
+}
+
 // Takes the request when the fast path applies (nx % 4 == 0, 16-byte aligned
 // bases and strides); otherwise leaves *handled false and the caller falls
 // back to the one-lane-per-cell kernel.
@@ -850,13 +930,13 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     return hipSuccess;
   if (prm.in_level_stride % 4 != 0 || prm.out_level_stride % 4 != 0)
     return hipSuccess;
-  if (std::getenv("MIFC_FORCE_CELL_KERNEL"))
+  if (env().force_cell_kernel)
     return hipSuccess;
 
   Tuning t = current_tuning(nx);
   while (t.WPB > 1 && t.WPB / 2 >= prm.nlev)
     t.WPB /= 2; // fewer levels than waves: do not launch waves that only stage map factors
-  if (!std::getenv("MIFC_VORTDIV_TUNE")) {
+  if (!env().has_vortdiv_tune) {
     // A small launch (the reference's single-field call: one level) is latency-bound: shorter
     // bands put more waves on the chip, and their halo re-reads stay in L2.
     // One 1440x720 level: 8-row bands 270 waves, 2-row bands 1077; 8 levels (a chunk of the host pipeline) keep 8.
@@ -882,6 +962,10 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.lo = (prm.j0 >= 1) ? 0 : (1 - prm.j0);
   const int last = rp.nyg - 1 - prm.j0; // local index of the global last row
   rp.hi = (rp.ny_local < last) ? rp.ny_local : last;
+  if (prm.row_end > prm.row_begin) { // a caller-chosen range of owned rows (halo overlap)
+    rp.lo = rp.lo > prm.row_begin ? rp.lo : prm.row_begin;
+    rp.hi = rp.hi < prm.row_end ? rp.hi : prm.row_end;
+  }
   if (rp.hi <= rp.lo) {
     // slab without a single computed row (can only be a 1-row edge slab): not supported here
     return hipSuccess;
@@ -909,9 +993,13 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.xcd_remap = t.XCD;
   rp.zigzag = t.ZZ;
   rp.nt_interior = t.NTI;
+  rp.lgroup = t.LG > 0 ? t.LG : 0;
+#ifdef MIFC_MEASUREMENT_BUILD
   rp.exp_nohalo = t.XH;
   rp.exp_nostore = t.XS;
   rp.exp_noload = t.XL;
+  rp.exp_store_aux = t.STA;
+#endif
   rp.u = prm.f0;
   rp.v = prm.f1;
   rp.xm = prm.xmapr;
@@ -998,6 +1086,23 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
 #undef ONESHOT
       }
       return hipGetLastError();
+    }
+  }
+  if (t.K == 2 && !rp.fc && prm.op != ST_JACOBIAN && t.RB == 14) { // one-shot tiles of 14 rows (16-wave workgroups)
+    constexpr int RB = 14;
+    rp.uB = (rp.hi - rp.lo + RB - 1) / RB;
+    rp.uW = (nx + 255) / 256;
+    const long units = (long)prm.nlev * rp.uB * rp.uW;
+    if (units <= 0x3fffffffL) {
+      rp.n_logical = (int)units;
+      rp.per_xcd = (rp.n_logical + 7) / 8;
+      grid = rp.per_xcd * 8;
+      if (prm.every_level_all_defined && rv && dv)
+        hipLaunchKernelGGL((vortdiv_tile_kernel<false, true, true, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp);
+      else if (rv && dv)
+        hipLaunchKernelGGL((vortdiv_tile_kernel<true, true, true, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp);
+      if (rv && dv)
+        return hipGetLastError();
     }
   }
   if (t.K == 2 && !rp.fc && prm.op != ST_JACOBIAN) { // one-shot tiles: units are (level, block of 8 rows, 256-column segment)

@@ -38,25 +38,85 @@ def slab_rows(ny, world_size, rank):
     return j0, j1 - j0
 
 
-def exchange_halo_rows(fields_with_halo, rank, world_size, group=None):
+class HaloExchange:
+    """One halo exchange in flight (begin_halo_exchange); wait() completes it.
+
+    With RCCL the transfers run on the communicator's own stream: wait() makes the
+    CURRENT stream wait for them (no host block), so kernels enqueued between begin and
+    wait overlap the exchange.  With gloo (CPU rehearsal; device tensors are staged
+    through host rows there) wait() blocks the host and copies the rows back."""
+
+    def __init__(self, reqs, staged):
+        self._reqs, self._staged = reqs, staged
+
+    def wait(self):
+        for req in self._reqs:
+            req.wait()
+        for dst, src in self._staged:
+            dst.copy_(src)
+        self._reqs, self._staged = [], []
+
+
+def begin_halo_exchange(fields_with_halo, rank, world_size, group=None):
     """fields_with_halo: list of tensors of shape (ny_local + 2, nx) whose rows
-    1..ny_local are owned.  Fills row 0 from the rank above (its last owned row)
-    and row ny_local+1 from the rank below (its first owned row).  The outermost
-    halo rows of the first / last rank are left as they are (never read)."""
+    1..ny_local are owned.  Starts filling row 0 from the rank above (its last owned
+    row) and row ny_local+1 from the rank below (its first owned row); the outermost
+    halo rows of the first / last rank are left as they are (never read).  Nearest
+    neighbour only: 2 messages of nx*4 bytes per field and neighbour (16 kB at nx=4000),
+    grouped into one RCCL group call."""
     import torch.distributed as dist
 
-    ops = []
+    via_host = str(dist.get_backend(group)).lower() != "nccl"
+    ops, staged = [], []
+
+    def send(row, peer):
+        ops.append(dist.P2POp(dist.isend, row.cpu() if (via_host and row.is_cuda) else row, peer, group))
+
+    def recv(row, peer):
+        if via_host and row.is_cuda:
+            import torch
+
+            buf = torch.empty(row.shape, dtype=row.dtype)
+            staged.append((row, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, peer, group))
+        else:
+            ops.append(dist.P2POp(dist.irecv, row, peer, group))
+
     for f in fields_with_halo:
         if rank > 0:
-            ops.append(dist.P2POp(dist.isend, f[1], rank - 1, group))
-            ops.append(dist.P2POp(dist.irecv, f[0], rank - 1, group))
+            send(f[1], rank - 1)
+            recv(f[0], rank - 1)
         if rank < world_size - 1:
-            ops.append(dist.P2POp(dist.isend, f[-2], rank + 1, group))
-            ops.append(dist.P2POp(dist.irecv, f[-1], rank + 1, group))
-    if not ops:
-        return
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
+            send(f[-2], rank + 1)
+            recv(f[-1], rank + 1)
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    return HaloExchange(reqs, staged)
+
+
+def exchange_halo_rows(fields_with_halo, rank, world_size, group=None):
+    """Blocking form of begin_halo_exchange()."""
+    begin_halo_exchange(fields_with_halo, rank, world_size, group).wait()
+
+
+def vortdiv_slab_overlapped(ctx, nx, ny_global, j0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, rank, world_size,
+                            fdefined_in=2, undef=1.0e35, n_undefined=None, group=None):
+    """One decomposed step of BASELINE.json config 4 on this rank's row slab: start the halo
+    exchange of u and v, compute the owned rows that read no halo row while it is in flight,
+    then the two boundary strips (mifc_vortdiv_slab_rows_enqueue).  Asynchronous on the
+    current stream; n_undefined (int64[1], device) receives this slab's undefined count."""
+    ex = begin_halo_exchange([u_halo, v_halo], rank, world_size, group)
+    b = 2  # strip height: keeps rows 0/1 and ny-2/ny-1 of the whole field together
+    if ny_local >= 3 * b + 1:
+        ok = ctx.vortdiv_slab_enqueue(nx, ny_global, j0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, fdefined_in=fdefined_in, undef=undef,
+                                      n_undefined=n_undefined, rows=(b, ny_local - b))
+        ex.wait()
+        for rows in ((0, b), (ny_local - b, ny_local)):
+            ok = ok and ctx.vortdiv_slab_enqueue(nx, ny_global, j0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, fdefined_in=fdefined_in,
+                                                 undef=undef, n_undefined=n_undefined, rows=rows, accumulate=True)
+        return ok
+    ex.wait()  # a thin slab: nothing worth overlapping
+    return ctx.vortdiv_slab_enqueue(nx, ny_global, j0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, fdefined_in=fdefined_in, undef=undef,
+                                    n_undefined=n_undefined)
 
 
 def _collective_device(group=None):

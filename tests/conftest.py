@@ -43,3 +43,28 @@ def gpu_ctx():
     ctx = fc.Context(0)  # raises without a GPU: GPU tests must not silently fall back
     yield ctx
     ctx.close()
+
+
+@pytest.fixture
+def mifc_env(gpu_ctx):
+    """Sets MIFC_* tuning variables for one test.  The library reads its environment when a
+    context is created (never per call), so the session context is told to re-read it; the
+    previous values are restored -- and re-read -- afterwards.  mifc_env(name, None) unsets."""
+    saved = {}
+
+    def set_var(name, value):
+        if name not in saved:
+            saved[name] = os.environ.get(name)
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = str(value)
+        gpu_ctx.reload_env()
+
+    yield set_var
+    for name, value in saved.items():
+        if value is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = value
+    gpu_ctx.reload_env()

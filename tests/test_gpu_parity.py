@@ -60,10 +60,10 @@ def test_stencils_device_resident(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("rows", ["1", "3", "8"])
-def test_scalar_row_kernels_band_heights(gpu_ctx, oracle, rows, monkeypatch):
+def test_scalar_row_kernels_band_heights(gpu_ctx, oracle, rows, mifc_env):
     """The one-input row-walking kernels pick their band height from the launch size; every height
     gives the reference result (the seeded cases are small, so the default runs 2-row bands)."""
-    monkeypatch.setenv("MIFC_SCALAR_ROWS_R", rows)
+    mifc_env("MIFC_SCALAR_ROWS_R", rows)
     ops = ("gradient", "plevelgwind_xcomp", "plevelgwind_ycomp", "plevelgvort", "ilevelgwind")
     for case in cases.stencil_cases(grids=[(8, 3), (64, 48), (516, 37)]):
         if case["op"] in ops:
@@ -71,11 +71,11 @@ def test_scalar_row_kernels_band_heights(gpu_ctx, oracle, rows, monkeypatch):
 
 
 @pytest.mark.parametrize("fused", ["1", "0"])
-def test_shapiro_filter_one_launch_and_four(gpu_ctx, oracle, fused, monkeypatch):
+def test_shapiro_filter_one_launch_and_four(gpu_ctx, oracle, fused, mifc_env):
     """The four sweeps in one launch (tiles of 240 columns, bands of rows) == the sweep-by-sweep path == the reference."""
     import mi_fieldcalc_amd.synth as synth
 
-    monkeypatch.setenv("MIFC_SHAPIRO_FUSED", fused)
+    mifc_env("MIFC_SHAPIRO_FUSED", fused)
     for nx, ny in [(4, 3), (8, 5), (236, 7), (240, 9), (244, 12), (484, 5), (128, 301), (1440, 37), (5000, 4)]:
         z = synth.scalar_field(nx, ny, 3 * nx + ny)
         for mode in cases.MODES:
@@ -85,10 +85,10 @@ def test_shapiro_filter_one_launch_and_four(gpu_ctx, oracle, fused, monkeypatch)
 
 
 @pytest.mark.parametrize("tune", ["K=1", "K=2", "R=8", "R=2,WPB=1"])
-def test_single_field_wind_operators_in_every_kernel_form(gpu_ctx, oracle, tune, monkeypatch):
+def test_single_field_wind_operators_in_every_kernel_form(gpu_ctx, oracle, tune, mifc_env):
     """relvort / divergence / absvort / jacobian through the C ABI's single-field calls: the launcher picks the
     one-shot, the one-shot-tile or the row-walking form by launch size; forced here, all give the reference."""
-    monkeypatch.setenv("MIFC_VORTDIV_TUNE", tune)
+    mifc_env("MIFC_VORTDIV_TUNE", tune)
     ops = ("relvort", "divergence", "absvort", "jacobian")
     for case in cases.stencil_cases(grids=[(8, 3), (64, 48), (260, 11), (516, 37)]):
         if case["op"] in ops:
@@ -357,12 +357,13 @@ def _expect_levels(oracle, u, v, xm, ym, flags):
 
 
 @pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 9), (516, 70, 6), (260, 11, 5), (17, 9, 7), (1440, 75, 5)])
-@pytest.mark.parametrize("tune", ["", "R=7,D=0", "R=5,D=1,NT=1", "R=64,D=1,WPB=8", "K=1", "K=1,XCD=0,NT=0", "K=2", "K=2,XCD=0", "R=1", "R=2,WPB=2", "R=8"])
-def test_vortdiv_levels_matches_per_level_reference_calls(gpu_ctx, oracle, nx, ny, nlev, tune, monkeypatch):
+@pytest.mark.parametrize("tune", ["", "R=7,D=0", "R=5,D=1,NT=1", "R=64,D=1,WPB=8", "K=1", "K=1,XCD=0,NT=0", "K=2", "K=2,XCD=0", "R=1", "R=2,WPB=2", "R=8",
+                                  "K=2,LG=8", "K=2,LG=4,XCD=0", "K=1,LG=3", "K=2,RB=14", "K=2,RB=14,LG=16"])
+def test_vortdiv_levels_matches_per_level_reference_calls(gpu_ctx, oracle, nx, ny, nlev, tune, mifc_env):
     import torch
 
     if tune:
-        monkeypatch.setenv("MIFC_VORTDIV_TUNE", tune)
+        mifc_env("MIFC_VORTDIV_TUNE", tune)
     u, v, xm, ym, flags = _levels_inputs(nx, ny, nlev, 4242 + nx)
     rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
     # host pointers
@@ -385,7 +386,7 @@ def test_vortdiv_levels_all_defined_fast_path(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("nlev,want", [(21, ("rvort", "diverg")), (18, ("diverg",))])
-def test_vortdiv_levels_host_pipeline(gpu_ctx, oracle, nlev, want, monkeypatch):
+def test_vortdiv_levels_host_pipeline(gpu_ctx, oracle, nlev, want, mifc_env):
     """A host-resident batch above 64 MiB per field is streamed through the
     device in chunks (ragged last chunk here); results and flags must equal the
     whole-batch path and, on sampled levels, the reference's per-level calls."""
@@ -393,7 +394,7 @@ def test_vortdiv_levels_host_pipeline(gpu_ctx, oracle, nlev, want, monkeypatch):
     u, v, xm, ym, flags = _levels_inputs(nx, ny, nlev, 31337)
     kw = dict(fdefined=flags, want=want)
     (rv, dv), fo = gpu_ctx.vortdiv_levels(u, v, xm, ym, **kw)
-    monkeypatch.setenv("MIFC_HOST_PIPELINE", "0")
+    mifc_env("MIFC_HOST_PIPELINE", "0")
     (rv0, dv0), fo0 = gpu_ctx.vortdiv_levels(u, v, xm, ym, **kw)
     assert np.array_equal(fo, fo0)
     for a, b in ((rv, rv0), (dv, dv0)):
@@ -463,13 +464,13 @@ def test_vortdiv_enqueue_counts(gpu_ctx, oracle):
 @pytest.mark.parametrize("nx,ny,nslab", [(64, 40, 4), (260, 23, 3), (512, 64, 8), (33, 17, 2)])
 @pytest.mark.parametrize("mode", ["all", "some"])
 @pytest.mark.parametrize("tune", [None, "K=2", "R=8"])
-def test_vortdiv_row_slabs_equal_whole_field(gpu_ctx, oracle, nx, ny, nslab, mode, tune, monkeypatch):
+def test_vortdiv_row_slabs_equal_whole_field(gpu_ctx, oracle, nx, ny, nslab, mode, tune, mifc_env):
     """Config 4 decomposition exercised on one GPU with a loop-back halo 'exchange' (the launcher picks the
     kernel form by launch size: the default, the one-shot tiles and the row-walking form all have to agree)."""
     import torch
 
     if tune is not None:
-        monkeypatch.setenv("MIFC_VORTDIV_TUNE", tune)
+        mifc_env("MIFC_VORTDIV_TUNE", tune)
 
     import mi_fieldcalc_amd as fc
     import mi_fieldcalc_amd.synth as synth
@@ -544,7 +545,7 @@ def test_hlevel_derived_levels(gpu_ctx, oracle, mode):
 
 
 @pytest.mark.parametrize("want", [("ff", "rh", "theta"), ("theta",)])
-def test_hlevel_derived_levels_host_pipeline(gpu_ctx, want, monkeypatch):
+def test_hlevel_derived_levels_host_pipeline(gpu_ctx, want, mifc_env):
     """The fused ff / RH / theta batch from host memory streams through the device in
     chunks (ragged last chunk); values and flags must equal the whole-batch path bit for bit."""
     import mi_fieldcalc_amd.synth as synth
@@ -561,7 +562,7 @@ def test_hlevel_derived_levels_host_pipeline(gpu_ctx, want, monkeypatch):
         t[l] = synth.sprinkle_undef(t[l], 60 + l, 0.02)
     kw = dict(fdef_wind=fw, fdef_thermo=ft, want=want)
     res, flags = gpu_ctx.hlevel_derived_levels(u, v, t, q, ps, a, b, **kw)
-    monkeypatch.setenv("MIFC_HOST_PIPELINE", "0")
+    mifc_env("MIFC_HOST_PIPELINE", "0")
     res0, flags0 = gpu_ctx.hlevel_derived_levels(u, v, t, q, ps, a, b, **kw)
     for k in want:
         assert cases.same_bits(res[k], res0[k], nan_payload=False), k
@@ -569,7 +570,7 @@ def test_hlevel_derived_levels_host_pipeline(gpu_ctx, want, monkeypatch):
 
 
 # ------------------------------------------------------------------ headline size
-def test_headline_1440x720x137_properties(gpu_ctx, oracle):
+def test_headline_1440x720x137_properties(gpu_ctx, oracle, mifc_env):
     """Full BASELINE.json configuration on the device: sampled levels against the
     oracle bit for bit, every level through a size-independent property (the
     fused row-sliding kernel and the one-lane-per-cell kernel are independent
@@ -591,11 +592,9 @@ def test_headline_1440x720x137_properties(gpu_ctx, oracle):
         assert cases.same_bits(rv[l].cpu().numpy(), e, nan_payload=False)
         ok, e, _ = oracle.call("divergence", nx, ny, ul, vl, xm, ym, fdefined=ALL)
         assert cases.same_bits(dg[l].cpu().numpy(), e, nan_payload=False)
-    os.environ["MIFC_FORCE_CELL_KERNEL"] = "1"
-    try:
-        (rv2, dg2), _ = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
-    finally:
-        del os.environ["MIFC_FORCE_CELL_KERNEL"]
+    mifc_env("MIFC_FORCE_CELL_KERNEL", "1")
+    (rv2, dg2), _ = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
+    mifc_env("MIFC_FORCE_CELL_KERNEL", None)
     assert torch.equal(rv.view(torch.int32), rv2.view(torch.int32))
     assert torch.equal(dg.view(torch.int32), dg2.view(torch.int32))
     # edge rule of fillEdges on every level: rows 0 / ny-1 and columns 0 / nx-1 are copies
@@ -605,11 +604,9 @@ def test_headline_1440x720x137_properties(gpu_ctx, oracle):
     du[:, 100:110, 200:260] = float(cases.UNDEF)
     flags[:] = SOME
     (rv3, dg3), fo3 = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
-    os.environ["MIFC_FORCE_CELL_KERNEL"] = "1"
-    try:
-        (rv4, dg4), fo4 = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
-    finally:
-        del os.environ["MIFC_FORCE_CELL_KERNEL"]
+    mifc_env("MIFC_FORCE_CELL_KERNEL", "1")
+    (rv4, dg4), fo4 = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
+    mifc_env("MIFC_FORCE_CELL_KERNEL", None)
     assert np.array_equal(fo3, fo4) and np.all(fo3 == SOME)
     assert torch.equal(rv3.view(torch.int32), rv4.view(torch.int32)) and torch.equal(dg3.view(torch.int32), dg4.view(torch.int32))
     l = 5
@@ -662,10 +659,10 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev):
 # ------------------------------------------------------------------ fused stencil-of-a-stencil kernels (mifc_fused2.hip)
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("device", [False, True])
-def test_fused_tfp_and_qvector(gpu_ctx, oracle, fused, device, monkeypatch):
+def test_fused_tfp_and_qvector(gpu_ctx, oracle, fused, device, mifc_env):
     """One launch with the intermediate fields in LDS == the reference's pass-by-pass result, flags
     included; MIFC_FUSED2=0 runs the multi-pass path on the same cases."""
-    monkeypatch.setenv("MIFC_FUSED2", fused)
+    mifc_env("MIFC_FUSED2", fused)
     for case in cases.fused2_cases():
         _check_case(gpu_ctx, oracle, case, device=device)
 
@@ -726,7 +723,7 @@ def test_fused_tfp_and_qvector_random_shapes(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("mode", ["all", "some"])
-def test_one_launch_kernels_equal_their_multi_pass_paths_on_a_large_field(gpu_ctx, mode, monkeypatch):
+def test_one_launch_kernels_equal_their_multi_pass_paths_on_a_large_field(gpu_ctx, mode, mifc_env):
     """1440 x 11520 (16 levels seen as one tall field, far beyond what the CPU oracle checks in seconds): the
     one-launch forms of thermalFrontParameter, plevelqvector and shapiro2_filter give bit for bit what the
     pass-by-pass kernels give (which the seeded cases pin to the reference), flags included."""
@@ -749,7 +746,7 @@ def test_one_launch_kernels_equal_their_multi_pass_paths_on_a_large_field(gpu_ct
 
     def run(env):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            mifc_env(k, v)
         out = {}
         out["tfp"] = gpu_ctx.thermalFrontParameter(dz, dxm, dym, fdefined=flag)
         for c in (1, 4):

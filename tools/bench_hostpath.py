@@ -50,10 +50,12 @@ def main():
 
     for pipe in ("1",) if a.only_batched else ("1", "0"):
         os.environ["MIFC_HOST_PIPELINE"] = pipe
+        ctx.reload_env()
         dt = timed(batched, a.reps)
         print(json.dumps({"case": "vortdiv_levels host pointers, " + ("chunked full-duplex pipeline" if pipe == "1" else "whole batch staged"),
                           "nlev": nlev, "ms": 1e3 * dt, "mcells_per_s": cells / dt / 1e6, "link_GBps_each_way": cells * 8 / dt / 1e9}), flush=True)
     os.environ["MIFC_HOST_PIPELINE"] = "1"
+    ctx.reload_env()
     if a.only_batched:
         return
 
@@ -68,11 +70,13 @@ def main():
 
     for pipe in ("1", "0"):
         os.environ["MIFC_HOST_PIPELINE"] = pipe
+        ctx.reload_env()
         dt = timed(derived, a.reps)
         print(json.dumps({"case": "hlevel_derived_levels (ff, RH, theta) host pointers, " + ("chunked full-duplex pipeline" if pipe == "1" else "whole batch staged"),
                           "nlev": nlev, "ms": 1e3 * dt, "mcells_per_s": cells / dt / 1e6, "in_GBps": cells * 16 / dt / 1e9, "out_GBps": cells * 12 / dt / 1e9}),
               flush=True)
     os.environ["MIFC_HOST_PIPELINE"] = "1"
+    ctx.reload_env()
     del t, q, outs
 
     nl = min(nlev, 16)

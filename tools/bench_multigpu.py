@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""N-rank drivers of the two multi-GPU configurations of BASELINE.json, one process per GPU:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P tools/bench_multigpu.py --config 4|5 [--steps K --warmup W] [--check] [--dump DIR]
+
+config 4  one 4000x4000 field split into N row slabs (STRONG scaling: the field is fixed).
+          A step = RCCL halo exchange of u and v (one row per neighbour and field, over xGMI)
+          overlapped with the interior rows of the slab kernel, then the two boundary strips,
+          then -- in the tested variant -- an 8-byte all-reduce of the undefined counts.
+          --check: rank 0 also computes the whole field on its own GPU and every slab is
+          compared with it bit for bit (values and the global undefined count).
+config 5  51 ensemble members x 137 levels x 1440x720, members sharded over the ranks
+          (STRONG scaling: 51 members in total, no data-path collective).  Per member: the
+          fused derived batch (ff, RH, theta; mifc_hlevel_derived_levels) and the fused
+          vorticity+divergence batch.  Every rank rotates over two resident member-sized
+          buffer sets (10 GB) so that no pass is served from the 256 MB Infinity Cache.
+          --check: rank r compares sampled levels of its first member between the
+          batched kernels and the single-field entry points (independent kernels).
+
+Rank 0 prints ONE JSON line (value = whole-job Mcells/s, max over ranks of the
+barrier-bracketed wall time).  MIFC_BENCH_BACKEND=gloo rehearses the control flow on a
+one-GPU box (ranks share cuda:0, halo rows staged through the host)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def setup():
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MIFC_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return world, rank, dev_index, dev, backend
+
+
+def max_over_ranks(x, dev, backend):
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def all_true(ok, dev, backend):
+    import torch
+    import torch.distributed as dist
+
+    t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def timed_steps(step, steps, warmup):
+    import torch
+    import torch.distributed as dist
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    return time.perf_counter() - t0
+
+
+# ------------------------------------------------------------------ config 4
+def config4(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+    from mi_fieldcalc_amd.sharding import global_undefined_count, slab_rows, vortdiv_slab_overlapped
+
+    world, rank, dev_index, dev, backend = setup()
+    nx = ny = args.size
+    j0, nloc = slab_rows(ny, world, rank)
+    # the whole field is generated on every rank from the seed (closed-form waves + seeded noise) and cut:
+    # what a rank keeps resident is its slab (+ halo rows, filled by the exchange)
+    xm, ym, _ = synth.grid_maps(nx, ny, h=2500.0)
+    u, v = synth.wind(nx, ny, 0x5EED0000 + 4000)
+    tested = not args.all_defined
+    if tested:
+        u = synth.sprinkle_undef(u, 41, 0.001)
+    flag = fc.SOME_DEFINED if tested else fc.ALL_DEFINED
+
+    def slab_with_halo(a):
+        t = torch.zeros((nloc + 2, nx), dtype=torch.float32, device=dev)
+        t[1:-1] = torch.from_numpy(a[j0:j0 + nloc]).to(dev)
+        return t
+
+    uh, vh = slab_with_halo(u), slab_with_halo(v)
+    dxm, dym = torch.from_numpy(np.ascontiguousarray(xm[j0:j0 + nloc])).to(dev), torch.from_numpy(np.ascontiguousarray(ym[j0:j0 + nloc])).to(dev)
+    rv = torch.empty((nloc, nx), dtype=torch.float32, device=dev)
+    dg = torch.empty_like(rv)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    ctx = fc.Context(dev_index)
+    ctx.use_torch_stream()
+
+    def step():
+        if not vortdiv_slab_overlapped(ctx, nx, ny, j0, nloc, uh, vh, dxm, dym, rv, dg, rank, world, fdefined_in=flag, n_undefined=cnt if tested else None):
+            raise RuntimeError(ctx.last_error())
+        if tested:
+            if backend == "nccl":
+                global_undefined_count(cnt)  # 8-byte all-reduce on the device (the next step zeroes the counter again)
+            else:
+                c = cnt.cpu()
+                global_undefined_count(c)
+
+    wall = max_over_ranks(timed_steps(step, args.steps, args.warmup), dev, backend)
+
+    out = {
+        "metric": "Mcells/s fused vorticity+divergence, one %dx%d field in %d row slabs (BASELINE.json configs[3])" % (nx, ny, world),
+        "value": round(nx * ny * args.steps / wall / 1e6, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "dtype": "f32 in/out, f64 combine",
+        "data": "synthetic",
+        "config": {"workload": "%dx%d float32 single level, row slabs of %d..%d rows, 1-row halo of u and v per neighbour exchanged each step "
+                               "(RCCL send/recv, overlapped with the interior rows), %s" % (
+                                   nx, ny, ny // world, -(-ny // world), "per-cell undefined tests + 8-byte count all-reduce" if tested else "ALL_DEFINED inputs"),
+                   "backend": backend},
+    }
+    if args.check:
+        # one more decomposed pass, then every slab against rank 0's whole-field result, bit for bit
+        cnt.zero_()
+        assert vortdiv_slab_overlapped(ctx, nx, ny, j0, nloc, uh, vh, dxm, dym, rv, dg, rank, world, fdefined_in=flag, n_undefined=cnt if tested else None)
+        torch.cuda.synchronize()
+        total = cnt.clone() if backend == "nccl" else cnt.cpu()
+        global_undefined_count(total)
+        ok = True
+        whole = None
+        if rank == 0:
+            du, dv_ = torch.from_numpy(u).to(dev)[None], torch.from_numpy(v).to(dev)[None]
+            fx, fy = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
+            (wrv, wdg), wflag = ctx.vortdiv_levels(du, dv_, fx, fy, fdefined=[flag])
+            whole = (wrv[0], wdg[0], int(wflag[0]))
+            ctx.use_torch_stream()
+        # gather the slabs on rank 0 (through the host: this is the checker, not the timed path)
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object((j0, nloc, rv.cpu().numpy(), dg.cpu().numpy()), parts, dst=0)
+        if rank == 0:
+            got_rv = np.empty((ny, nx), np.float32)
+            got_dg = np.empty((ny, nx), np.float32)
+            for pj0, pn, prv, pdg in parts:
+                got_rv[pj0:pj0 + pn], got_dg[pj0:pj0 + pn] = prv, pdg
+            wrv_h, wdg_h = whole[0].cpu().numpy(), whole[1].cpu().numpy()
+            same = lambda a, b: bool(np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(b)]) and np.array_equal(np.isnan(a), np.isnan(b)))
+            got_flag = fc.ALL_DEFINED if not tested else fc.classify(int(total.item()), nx * ny - 2 * nx)
+            ok = same(got_rv, wrv_h) and same(got_dg, wdg_h) and got_flag == whole[2]
+            out["verified"] = ok
+            out["check"] = "every slab == rank 0's whole-field result bit for bit; global undefined count %d -> flag %d" % (int(total.item()), got_flag)
+            if args.dump:
+                os.makedirs(args.dump, exist_ok=True)
+                np.save(os.path.join(args.dump, "config4_rvort.npy"), got_rv)
+                np.save(os.path.join(args.dump, "config4_diverg.npy"), got_dg)
+                with open(os.path.join(args.dump, "config4_meta.json"), "w") as f:
+                    json.dump({"nx": nx, "ny": ny, "seed": 0x5EED0000 + 4000, "tested": tested, "flag": got_flag, "count": int(total.item())}, f)
+        ok = all_true(ok, dev, backend)
+        if rank == 0 and not ok:
+            out["verified"] = False
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+        if args.check and not out.get("verified", False):
+            sys.exit(1)
+
+
+# ------------------------------------------------------------------ config 5
+def config5(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+    from mi_fieldcalc_amd.sharding import shard_range
+
+    world, rank, dev_index, dev, backend = setup()
+    nx, ny, nlev, nmem = 1440, 720, args.nlev, args.members
+    m0, m1 = shard_range(nmem, world, rank)
+    ctx = fc.Context(dev_index)
+    ctx.use_torch_stream()
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    dxm, dym = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
+    al, bl = synth.hybrid_levels(nlev)
+    flags = np.full(nlev, fc.ALL_DEFINED, np.int32)
+    nsets = 2 if backend == "nccl" or world == 1 else 1  # gloo rehearsal: the ranks share one GPU's memory
+    sets = []
+    for s in range(nsets):
+        u, v = synth.device_wind(nx, ny, nlev, 0x5EED0000 + 5000 + 97 * rank + s, dev)
+        t, q, ps = synth.device_thermo(nx, ny, nlev, 0x5EED0000 + 5500 + 97 * rank + s, dev)
+        outs = [torch.empty_like(u) for _ in range(5)]
+        sets.append(dict(u=u, v=v, t=t, q=q, ps=ps, ff=outs[0], rh=outs[1], th=outs[2], rv=outs[3], dg=outs[4],
+                         cnt=torch.zeros(3 * nlev, dtype=torch.int64, device=dev)))
+
+    def member_pass(k):
+        s = sets[k % nsets]
+        ok = ctx.hlevel_derived_levels_enqueue(s["u"], s["v"], s["t"], s["q"], s["ps"], al, bl, s["ff"], s["rh"], s["th"], s["cnt"],
+                                               fdef_wind=flags, fdef_thermo=flags)
+        ok = ok and ctx.vortdiv_levels_enqueue(s["u"], s["v"], dxm, dym, s["rv"], s["dg"], fdefined=flags)
+        if not ok:
+            raise RuntimeError(ctx.last_error())
+
+    def step():  # one pass over this rank's share of the ensemble
+        for k in range(m1 - m0):
+            member_pass(k)
+
+    wall = max_over_ranks(timed_steps(step, args.steps, args.warmup), dev, backend)
+    cells = nx * ny * nlev * nmem
+    out = {
+        "metric": "Mcells/s derived (ff, RH, theta) + vorticity/divergence pipeline, %d members x 1440x720x%d (BASELINE.json configs[4])" % (nmem, nlev),
+        "value": round(cells * args.steps / wall / 1e6, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "dtype": "f32 (f64 combine / x^kappa)",
+        "data": "synthetic",
+        "config": {"workload": "%d members sharded over %d ranks (%d on the busiest), per member 2 launches over %d levels: fused ff+RH+theta (28 B/cell) and "
+                               "fused relvort+divergence (16 B/cell); inputs ALL_DEFINED, resident in HBM, two rotating member-sized buffer sets per rank" % (
+                                   nmem, world, -(-nmem // world), nlev),
+                   "algorithmic_bytes_per_member": nx * ny * nlev * 44 + 3 * nx * ny * 4, "backend": backend},
+    }
+    if args.check:
+        # sampled levels of this rank's first member: batched kernels == single-field entry points
+        s = sets[0]
+        member_pass(0)
+        torch.cuda.synchronize()
+        ok = True
+        same = lambda a, b: bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
+        for l in sorted({0, nlev // 2, nlev - 1}):
+            r1, _ = ctx.relvort(s["u"][l], s["v"][l], dxm, dym, fdefined=fc.ALL_DEFINED)
+            d1, _ = ctx.divergence(s["u"][l], s["v"][l], dxm, dym, fdefined=fc.ALL_DEFINED)
+            f1, _ = ctx.vectorabs(s["u"][l], s["v"][l], fdefined=fc.ALL_DEFINED)
+            h1, _ = ctx.hlevelhum(s["t"][l], s["q"][l], s["ps"], float(al[l]), float(bl[l]), "", 1, fdefined=fc.ALL_DEFINED)
+            t1, _ = ctx.hleveltemp(s["t"][l], s["ps"], float(al[l]), float(bl[l]), "", 3, fdefined=fc.ALL_DEFINED)
+            ok = ok and same(r1, s["rv"][l]) and same(d1, s["dg"][l]) and same(f1, s["ff"][l]) and same(h1, s["rh"][l]) and same(t1, s["th"][l])
+        ctx.use_torch_stream()
+        ok = all_true(ok, dev, backend)
+        out["verified"] = ok
+        out["check"] = "levels 0 / mid / last of every rank's first member: batched kernels == single-field kernels bit for bit"
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+        if args.check and not out.get("verified", False):
+            sys.exit(1)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, choices=(4, 5), required=True)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--dump", default=None, help="config 4 + --check: directory for the assembled result (rank 0)")
+    ap.add_argument("--size", type=int, default=4000, help="config 4: the field is size x size")
+    ap.add_argument("--all-defined", action="store_true", help="config 4: ALL_DEFINED inputs (no tests, no count all-reduce)")
+    ap.add_argument("--members", type=int, default=51, help="config 5")
+    ap.add_argument("--nlev", type=int, default=137, help="config 5")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.config == 4 else 3
+    (config4 if args.config == 4 else config5)(args)
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,7 @@ def timed(fn, n=21):
 for env in ({}, {"MIFC_SCALAR_ROWS_R": "8"}):
     os.environ.pop("MIFC_SCALAR_ROWS_R", None)
     os.environ.update(env)
+    ctx.reload_env()
     for name, nbytes, call in (
         ("gradient c=3", 16, lambda s: ctx.gradient(s[0], s[1], s[2], 3, fdefined=fc.ALL_DEFINED, out=s[4])),
         ("plevelgvort", 20, lambda s: ctx.plevelgvort(s[0], s[1], s[2], s[3], fdefined=fc.ALL_DEFINED, out=s[4])),

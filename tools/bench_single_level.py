@@ -47,6 +47,7 @@ for name, env in configs:
     for k in ("MIFC_FUSED2", "MIFC_FUSED2_BAND"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    ctx.reload_env()
     tfp = lambda: ctx.thermalFrontParameter(z, dxm, dym, fdefined=fc.ALL_DEFINED, out=out)
     qv = lambda: ctx.plevelqvector(z, t, dxm, dym, dfc, 500.0, 1, fdefined=fc.ALL_DEFINED, out=out)
     print("%-22s  TFP %7.1f / %6.1f   Q-vector %7.1f / %6.1f" % (name, timed(tfp), kernel_us(tfp), timed(qv), kernel_us(qv)))
@@ -54,6 +55,7 @@ for name, env in configs:
 # ---- the other hot-path operators on one level (default settings)
 for k in ("MIFC_FUSED2", "MIFC_FUSED2_BAND"):
     os.environ.pop(k, None)
+ctx.reload_env()
 u_np, v_np = synth.wind(NX, NY, 11)
 u, v = torch.from_numpy(u_np).to(dev), torch.from_numpy(v_np).to(dev)
 q = torch.full_like(z, 0.004)

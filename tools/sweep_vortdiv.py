@@ -12,6 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the measurement build of the library: the only one that contains the XH / XS / XL / PADROWS knobs
+os.environ.setdefault("MIFC_LIB_PATH", os.path.join(ROOT, "mi-fieldcalc_amd", "libmifc_measure.so"))
 
 import torch  # noqa: E402
 
@@ -47,7 +49,6 @@ YARD = {
 
 
 def main():
-    os.environ["MIFC_MEASUREMENT_KNOBS"] = "1"  # XH / XS / PADROWS: timing experiments that give wrong results by design
     tunes = sys.argv[1:] or ["R=8"]
     dev = torch.device("cuda", 0)
     xm, ym, _ = synth.grid_maps(NX, NY)
@@ -63,6 +64,7 @@ def main():
 
     def run(tune):
         os.environ["MIFC_VORTDIV_TUNE"] = tune
+        ctx.reload_env()
         assert ctx.vortdiv_levels_enqueue(du, dv, dxm, dym, rv, dg, fdefined=flags)
 
     for t in tunes:  # warm-up + first-use
@@ -85,7 +87,7 @@ def main():
         e.record()
         torch.cuda.synchronize()
         copy_ms.append(s.elapsed_time(e) / INNER)
-        for key in YARD:
+        for key in (YARD if not os.environ.get("SWEEP_NO_YARD") else {"stream2 plain, 1 lane/16B": (0, 0), "stream2 nt-ld+st, 1 lane/16B": (2, 0)}):
             variant, blocks = YARD[key]
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -103,6 +105,8 @@ def main():
     med = float(np.median(copy_ms))
     print("%-28s %9.4f %9.4f %9.1f %7.4f   (2x torch copy_, same u+v -> 2 outputs bytes)" % ("d2d copy", med, float(np.min(copy_ms)), cb / med / 1e6, cb / med / 1e6 / 8000.0))
     for key in YARD:
+        if not yard_ms[key]:
+            continue
         med = float(np.median(yard_ms[key]))
         print("%-28s %9.4f %9.4f %9.1f %7.4f   (2-in/2-out float4 stream, no arithmetic)" % (key, med, float(np.min(yard_ms[key])), cb / med / 1e6, cb / med / 1e6 / 8000.0))
 
