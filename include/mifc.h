@@ -301,10 +301,25 @@ enum {
   MIFC_OP_RELVORT = 0, MIFC_OP_ABSVORT = 1, MIFC_OP_DIVERGENCE = 2, MIFC_OP_VORTDIV = 3,
   MIFC_OP_GRADIENT_X = 4, MIFC_OP_GRADIENT_Y = 5, MIFC_OP_GRADIENT_ABS = 6, MIFC_OP_GRADIENT_LAPLACE = 7,
   MIFC_OP_GWIND_X = 8, MIFC_OP_GWIND_Y = 9, MIFC_OP_GVORT = 10, MIFC_OP_IGWIND = 11,
-  MIFC_OP_JACOBIAN = 13
+  MIFC_OP_JACOBIAN = 13,
+  /* mifc_stencil_levels_ex only: */
+  MIFC_OP_ADVECTION = 12, MIFC_OP_TFP = 14, MIFC_OP_QVECTOR = 15, MIFC_OP_SHAPIRO2 = 17
 };
 int mifc_stencil_levels(mifc_ctx* ctx, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* xmapr, const float* ymapr,
                         const float* fcoriolis, float* out0, float* out1, int* fdefined, float undef, int memkind);
+
+/* The same plus the rest of the stencil family over a batch of levels, the map
+ * and Coriolis fields shared by all levels:
+ *   MIFC_OP_ADVECTION .cc:1942  f0 = f, f1 = u, f2 = v, scalar = hours
+ *   MIFC_OP_TFP       .cc:2266  f0 = tx                         (thermalFrontParameter)
+ *   MIFC_OP_QVECTOR   .cc:505   f0 = z, f1 = t, level_scalars = host float[nlev] pressures p, compute 1..4
+ *   MIFC_OP_SHAPIRO2  .cc:2076  f0 = field (out0 == f0 allowed; no map fields)
+ * Every other op is forwarded to mifc_stencil_levels.  Per level the result and the flag are those
+ * of the single-field reference call; the two-stage operators run as ONE launch per flag group
+ * (levels whose input is ALL_DEFINED / the others) with their intermediate fields in LDS. */
+int mifc_stencil_levels_ex(mifc_ctx* ctx, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* f2, const float* xmapr,
+                           const float* ymapr, const float* fcoriolis, const float* level_scalars, float scalar, int compute, float* out0,
+                           float* out1, int* fdefined, float undef, int memkind);
 
 /* Fused derived variables on hybrid model levels: one pass producing any of
  *   ff    = vectorabs(u, v)                                   (.cc:1819)
@@ -324,6 +339,32 @@ int mifc_hlevel_derived_levels(mifc_ctx* ctx, int nx, int ny, int nlev, const fl
 int mifc_hlevel_derived_levels_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q,
                                        const float* ps, const float* alevel, const float* blevel, float* ff, float* rh, float* theta,
                                        const int* fdef_wind, const int* fdef_thermo, float undef, unsigned long long* n_undefined_dev);
+
+/* The general form: per level l, any subset of
+ *   ff   = vectorabs(u, v)                                               (.cc:1819)
+ *   temp = hleveltemp(t, ps, a_l, b_l, temp_unit, temp_compute)          (.cc:1046; compute 1..5)
+ *   hum  = hlevelhum(t, h, ps, a_l, b_l, hum_unit, hum_compute)          (.cc:1145; compute 1..12)
+ *   hum2 = hlevelhum(t, h, ps, a_l, b_l, hum2_unit, hum2_compute)        a second variant of the SAME inputs,
+ *          e.g. hum = RH (compute 1) and hum2 = dew point (compute 9) from T and q
+ * in ONE pass over u, v, t, h ([nlev][ny][nx]; h = specific humidity or RH as the variants demand; ps [ny][nx]
+ * shared).  NULL outputs are skipped (their inputs are not read); unit / compute arguments of a skipped
+ * output are ignored.  Results and flags per level are those of the per-level reference calls.  Returns 0
+ * where one of those calls would return false (bad (a, b) pair .cc:298, compute out of range) and for
+ * temp_compute outside 1..5 (the reference leaves such cells unwritten, .cc:1080-1090).
+ * fdef_wind / fdef_thermo: host int[nlev] input states of (u, v) and of (t, h, ps); fdef_ff, fdef_temp,
+ * fdef_hum, fdef_hum2: host int[nlev] results (may be NULL). */
+int mifc_hlevel_derived_batch(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* h,
+                              const float* ps, const float* alevel, const float* blevel, float* ff, float* temp, const char* temp_unit,
+                              int temp_compute, float* hum, const char* hum_unit, int hum_compute, float* hum2, const char* hum2_unit,
+                              int hum2_compute, const int* fdef_wind, const int* fdef_thermo, int* fdef_ff, int* fdef_temp, int* fdef_hum,
+                              int* fdef_hum2, float undef, int memkind);
+/* Asynchronous, device pointers only.  n_undefined_dev: device u64[4*nlev] laid out
+ * [ff | temp | hum | hum2], zeroed by the call; classify against nx*ny. */
+int mifc_hlevel_derived_batch_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* h,
+                                      const float* ps, const float* alevel, const float* blevel, float* ff, float* temp, const char* temp_unit,
+                                      int temp_compute, float* hum, const char* hum_unit, int hum_compute, float* hum2, const char* hum2_unit,
+                                      int hum2_compute, const int* fdef_wind, const int* fdef_thermo, float undef,
+                                      unsigned long long* n_undefined_dev);
 
 /* ---- horizontally decomposed single field (row slabs) -------------------- */
 /* Vorticity + divergence on one row slab of a larger field (config 4 of

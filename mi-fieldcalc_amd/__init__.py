@@ -540,6 +540,36 @@ class Context:
         r1 = None if not two else (out1 if _is_torch(out1) else o1.keep)
         return (r0, r1), flags
 
+    OPS_EX = {"advection": 12, "thermalFrontParameter": 14, "plevelqvector": 15, "shapiro2_filter": 17}
+
+    def stencil_levels_ex(self, op, f0, f1=None, f2=None, xmapr=None, ymapr=None, fcoriolis=None, level_scalars=None, scalar=0.0, compute=0,
+                          fdefined=None, undef=UNDEF, out0=None):
+        """The f1 operators over a level batch (mifc_stencil_levels_ex): op in OPS_EX; fields (nlev, ny, nx),
+        map / Coriolis fields (ny, nx) shared.  advection: f0 = f, f1 = u, f2 = v, scalar = hours;
+        thermalFrontParameter: f0 = tx; plevelqvector: f0 = z, f1 = t, level_scalars = p per level, compute 1..4;
+        shapiro2_filter: f0 = field.  Returns (out0, flags) or None."""
+        code = self.OPS_EX[op]
+        a0, a1, a2 = _Arg(f0), _Arg(f1, allow_none=True), _Arg(f2, allow_none=True)
+        ax, ay, af = _Arg(xmapr, allow_none=True), _Arg(ymapr, allow_none=True), _Arg(fcoriolis, allow_none=True)
+        if len(a0.shape) != 3:
+            raise ValueError("level fields must be (nlev, ny, nx)")
+        nlev, ny, nx = a0.shape
+        if out0 is None:
+            out0 = _empty_like(f0)
+        o0 = _Arg(out0, output=True)
+        if not _same_shape([a1, a2, o0], a0.shape) or not _same_shape([ax, ay, af], (ny, nx)):
+            raise ValueError("level fields must be (nlev, ny, nx) and the map / Coriolis fields (ny, nx)")
+        mk = _memkind([a0, a1, a2, ax, ay, af, o0], self.device)
+        self._bind_stream(mk)
+        flags = np.full(nlev, SOME_DEFINED, dtype=np.int32) if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
+        ls = None if level_scalars is None else np.ascontiguousarray(level_scalars, dtype=np.float32).reshape(nlev)
+        rc = self._call("mifc_stencil_levels_ex", [code, nx, ny, nlev, a0.addr, a1.addr, a2.addr, ax.addr, ay.addr, af.addr,
+                                                   None if ls is None else ls.ctypes.data, float(scalar), int(compute), o0.addr, None,
+                                                   flags.ctypes.data, float(undef), mk])
+        if not rc:
+            return None
+        return (out0 if _is_torch(out0) else o0.keep), flags
+
     def vortdiv_levels_enqueue(self, u, v, xmapr, ymapr, rvort, diverg, fdefined=None, undef=UNDEF, n_undefined=None):
         """Asynchronous form on device tensors; n_undefined: int64 CUDA tensor[nlev] or None.
         u, v and rvort, diverg may be level-padded batches (see batch_empty)."""
@@ -615,6 +645,50 @@ class Context:
             return None
         res = {k: (out[k] if _is_torch(out[k]) else o[k].keep) for k in want}
         return res, {k: fo[k] for k in want}
+
+    def hlevel_derived_batch(self, u, v, t, h, ps, alevel, blevel, temp=None, hum=None, hum2=None, ff=True, fdef_wind=None, fdef_thermo=None,
+                             undef=UNDEF, out=None, enqueue_counts=None):
+        """The general fused derived batch (mifc_hlevel_derived_batch): per level any of
+          ff   = vectorabs(u, v)                         (ff=True)
+          temp = hleveltemp(t, ps, a, b, unit, compute)  (temp=(unit, compute))
+          hum  = hlevelhum(t, h, ps, a, b, unit, compute)   (hum=(unit, compute))
+          hum2 = a second hlevelhum variant of the same inputs (hum2=(unit, compute))
+        u, v, t, h: (nlev, ny, nx); ps: (ny, nx).  out: optional dict of preallocated outputs.
+        Returns ({name: array}, {name: flags}) or None.  With enqueue_counts (int64 CUDA tensor[4*nlev]) the call is
+        asynchronous on device tensors and returns the outputs only (counts: ff | temp | hum | hum2)."""
+        ref = next(x for x in (u, t) if x is not None)
+        nlev, ny, nx = _Arg(ref).shape
+        names = [k for k, w in (("ff", ff), ("temp", temp), ("hum", hum), ("hum2", hum2)) if w]
+        out = dict(out or {})
+        for k in names:
+            if out.get(k) is None:
+                out[k] = _empty_like(ref)
+        a = {k: _Arg(x, allow_none=True) for k, x in dict(u=u, v=v, t=t, h=h, ps=ps).items()}
+        o = {k: _Arg(out.get(k) if k in names else None, allow_none=True, output=True) for k in ("ff", "temp", "hum", "hum2")}
+        if not _same_shape([a[k] for k in ("u", "v", "t", "h")] + list(o.values()), (nlev, ny, nx)) or not _same_shape([a["ps"]], (ny, nx)):
+            raise ValueError("level fields must be (nlev, ny, nx) and ps (ny, nx)")
+        mk = _memkind(list(a.values()) + list(o.values()), self.device)
+        self._bind_stream(mk)
+        al = np.ascontiguousarray(alevel if alevel is not None else np.zeros(nlev), dtype=np.float32).reshape(nlev)
+        bl = np.ascontiguousarray(blevel if blevel is not None else np.ones(nlev), dtype=np.float32).reshape(nlev)
+        fw = np.full(nlev, SOME_DEFINED, np.int32) if fdef_wind is None else np.array(fdef_wind, np.int32).reshape(nlev).copy()
+        ft = np.full(nlev, SOME_DEFINED, np.int32) if fdef_thermo is None else np.array(fdef_thermo, np.int32).reshape(nlev).copy()
+        unit = lambda w: (w[0] if w else "").encode()
+        comp = lambda w: int(w[1]) if w else 0
+        common = [nx, ny, nlev, a["u"].addr, a["v"].addr, a["t"].addr, a["h"].addr, a["ps"].addr, al.ctypes.data, bl.ctypes.data,
+                  o["ff"].addr, o["temp"].addr, unit(temp), comp(temp), o["hum"].addr, unit(hum), comp(hum), o["hum2"].addr, unit(hum2), comp(hum2),
+                  fw.ctypes.data, ft.ctypes.data]
+        if enqueue_counts is not None:
+            if mk != MEM_DEVICE:
+                raise ValueError("the *_enqueue calls take device tensors only")
+            rc = self._call("mifc_hlevel_derived_batch_enqueue", common + [float(undef), enqueue_counts.data_ptr()])
+            return {k: out[k] for k in names} if rc else None
+        fo = {k: np.full(nlev, -1, np.int32) for k in ("ff", "temp", "hum", "hum2")}
+        rc = self._call("mifc_hlevel_derived_batch", common + [fo[k].ctypes.data for k in ("ff", "temp", "hum", "hum2")] + [float(undef), mk])
+        if not rc:
+            return None
+        res = {k: (out[k] if _is_torch(out[k]) else o[k].keep) for k in names}
+        return res, {k: fo[k] for k in names}
 
     def hlevel_derived_levels_enqueue(self, u, v, t, q, ps, alevel, blevel, ff, rh, theta, n_undefined, fdef_wind=None,
                                       fdef_thermo=None, undef=UNDEF):

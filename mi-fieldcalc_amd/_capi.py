@@ -121,6 +121,7 @@ SIGNATURES = {
     # batched
     "mifc_vortdiv_levels": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_stencil_levels": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_stencil_levels_ex": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "f", "i", "p", "p", "pi", "f", "i"]),
     "mifc_vortdiv_levels_enqueue": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "pu"]),
     "mifc_batch_level_stride": ("z", ["i", "i"]),
     "mifc_vortdiv_levels_strided_enqueue": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "z", "z", "pi", "f", "pu"]),
@@ -131,6 +132,15 @@ SIGNATURES = {
     "mifc_hlevel_derived_levels_enqueue": (
         "i",
         ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "p", "pi", "pi", "f", "pu"],
+    ),
+    "mifc_hlevel_derived_batch": (
+        "i",
+        ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "s", "i", "p", "s", "i", "p", "s", "i", "pi", "pi", "pi", "pi", "pi", "pi",
+         "f", "i"],
+    ),
+    "mifc_hlevel_derived_batch_enqueue": (
+        "i",
+        ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "s", "i", "p", "s", "i", "p", "s", "i", "pi", "pi", "f", "pu"],
     ),
     "mifc_vortdiv_slab_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu"]),
     "mifc_vortdiv_slab_rows_enqueue": ("i", ["ctx", "i", "i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu", "i"]),

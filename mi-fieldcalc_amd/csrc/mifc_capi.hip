@@ -62,8 +62,11 @@ bool ensure_levels(mifc_ctx* c, size_t nlev)
     (void)hipFree(c->d_counts);
   if (c->d_ab)
     (void)hipFree(c->d_ab);
+  if (c->d_levels)
+    (void)hipFree(c->d_levels);
   if (c->h_pinned)
     (void)hipHostFree(c->h_pinned);
+  c->d_levels = nullptr;
   c->d_flags = nullptr;
   c->d_counts = nullptr;
   c->d_ab = nullptr;
@@ -74,11 +77,13 @@ bool ensure_levels(mifc_ctx* c, size_t nlev)
     cap *= 2;
   if ((e = hipMalloc((void**)&c->d_flags, 2 * cap)) != hipSuccess)
     return fail(c, "hipMalloc(flags)", e);
-  if ((e = hipMalloc((void**)&c->d_counts, 3 * cap * sizeof(u64))) != hipSuccess)
+  if ((e = hipMalloc((void**)&c->d_counts, 4 * cap * sizeof(u64))) != hipSuccess)
     return fail(c, "hipMalloc(counts)", e);
   if ((e = hipMalloc((void**)&c->d_ab, 2 * cap * sizeof(float))) != hipSuccess)
     return fail(c, "hipMalloc(ab)", e);
-  if ((e = hipHostMalloc(&c->h_pinned, 3 * cap * sizeof(u64) + 2 * cap + 2 * cap * sizeof(float), hipHostMallocDefault)) != hipSuccess)
+  if ((e = hipMalloc((void**)&c->d_levels, cap * sizeof(int))) != hipSuccess)
+    return fail(c, "hipMalloc(levels)", e);
+  if ((e = hipHostMalloc(&c->h_pinned, 4 * cap * sizeof(u64) + 2 * cap + 2 * cap * sizeof(float), hipHostMallocDefault)) != hipSuccess)
     return fail(c, "hipHostMalloc", e);
   c->cap_lev = cap;
   return true;
@@ -119,11 +124,11 @@ u64* pinned_counts(mifc_ctx* c)
 }
 unsigned char* pinned_flags(mifc_ctx* c)
 {
-  return reinterpret_cast<unsigned char*>(c->h_pinned) + 3 * c->cap_lev * sizeof(u64);
+  return reinterpret_cast<unsigned char*>(c->h_pinned) + 4 * c->cap_lev * sizeof(u64);
 }
 float* pinned_ab(mifc_ctx* c)
 {
-  return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(c->h_pinned) + 3 * c->cap_lev * sizeof(u64) + 2 * c->cap_lev);
+  return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(c->h_pinned) + 4 * c->cap_lev * sizeof(u64) + 2 * c->cap_lev);
 }
 
 // Brings a field to the device if the caller handed a host pointer.
@@ -437,6 +442,8 @@ void mifc_destroy(mifc_ctx* c)
     (void)hipFree(c->d_counts);
   if (c->d_ab)
     (void)hipFree(c->d_ab);
+  if (c->d_levels)
+    (void)hipFree(c->d_levels);
   if (c->h_pinned)
     (void)hipHostFree(c->h_pinned);
   if (c->pinned_read)
@@ -1046,6 +1053,22 @@ static bool fused2_enabled()
   return mifc::env().fused2; // MIFC_FUSED2=0: always the multi-pass path (A/B measurements, tests)
 }
 
+// thermalFrontParameter pass by pass on device pointers: |grad T| into the context's scratch, then the
+// front parameter; the second pass takes its "all defined" from the flag the first one returned (:2286)
+static int tfp_two_passes(mifc_ctx* c, int nx, int ny, const float* d_tx, const float* d_xm, const float* d_ym, float* d_out, int* fdefined,
+                          float undef)
+{
+  const size_t n = (size_t)nx * ny;
+  if (!ensure_slot(c, 8, n * sizeof(float)))
+    return 0;
+  float* d_absdelt = static_cast<float*>(c->slot[8]);
+  const StencilCall pass1 = {mifc::ST_GRAD_ABS, nx, ny, 1, d_tx, nullptr, d_xm, d_ym, nullptr, d_absdelt, nullptr};
+  if (!run_stencil(c, pass1, fdefined, undef, MIFC_MEM_DEVICE))
+    return 0;
+  const StencilCall pass2 = {mifc::ST_TFP, nx, ny, 1, d_tx, d_absdelt, d_xm, d_ym, nullptr, d_out, nullptr};
+  return run_stencil(c, pass2, fdefined, undef, MIFC_MEM_DEVICE);
+}
+
 // thermalFrontParameter, FieldCalculations.cc:2266-2309.  One fused launch where
 // the grid allows it; otherwise two passes with an intermediate |grad T| field
 // that lives in the context's scratch.  The second pass takes its "all defined"
@@ -1088,14 +1111,7 @@ int mifc_thermalFrontParameter(mifc_ctx* c, int nx, int ny, const float* tx, con
       return 1;
     }
   }
-  if (!ensure_slot(c, 8, n * sizeof(float)))
-    return 0;
-  float* d_absdelt = static_cast<float*>(c->slot[8]);
-  const StencilCall pass1 = {mifc::ST_GRAD_ABS, nx, ny, 1, d_tx, nullptr, d_xm, d_ym, nullptr, d_absdelt, nullptr};
-  if (!run_stencil(c, pass1, fdefined, undef, MIFC_MEM_DEVICE))
-    return 0;
-  const StencilCall pass2 = {mifc::ST_TFP, nx, ny, 1, d_tx, d_absdelt, d_xm, d_ym, nullptr, d_out, nullptr};
-  if (!run_stencil(c, pass2, fdefined, undef, MIFC_MEM_DEVICE))
+  if (!tfp_two_passes(c, nx, ny, d_tx, d_xm, d_ym, d_out, fdefined, undef))
     return 0;
   if (!fetch_out(c, 5, tfp, n, memkind))
     return 0;
@@ -1210,6 +1226,179 @@ int mifc_stencil_levels(mifc_ctx* c, int op, int nx, int ny, int nlev, const flo
   return run_stencil(c, sc, fdefined, undef, memkind);
 }
 
+// ---- the f1 operators over a batch of levels (shared map factors) -----------------------------
+// advection runs on the batched stencil driver; thermalFrontParameter, plevelqvector and shapiro2_filter on
+// their one-launch kernels with grid.y = level, in two groups: the levels whose input flag is ALL_DEFINED
+// (no tests) and the others.  Grids those kernels do not take (nx % 4 != 0, unaligned) go level by level
+// through the single-field entry points.
+static int f1_levels_fallback(mifc_ctx* c, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* xm, const float* ym,
+                              const float* fc, const float* level_p, int compute, float* out0, int* fdefined, float undef)
+{
+  const size_t n = (size_t)nx * ny;
+  for (int l = 0; l < nlev; ++l) {
+    int rc;
+    if (op == MIFC_OP_TFP)
+      rc = mifc_thermalFrontParameter(c, nx, ny, f0 + l * n, xm, ym, out0 + l * n, fdefined + l, undef, MIFC_MEM_DEVICE);
+    else if (op == MIFC_OP_QVECTOR)
+      rc = mifc_plevelqvector(c, nx, ny, f0 + l * n, f1 + l * n, xm, ym, fc, level_p[l], compute, out0 + l * n, fdefined + l, undef, MIFC_MEM_DEVICE);
+    else
+      rc = mifc_shapiro2_filter(c, nx, ny, f0 + l * n, out0 + l * n, fdefined + l, undef, MIFC_MEM_DEVICE);
+    if (!rc)
+      return 0;
+  }
+  return 1;
+}
+
+int mifc_stencil_levels_ex(mifc_ctx* c, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* f2, const float* xmapr,
+                           const float* ymapr, const float* fcoriolis, const float* level_scalars, float scalar, int compute, float* out0,
+                           float* out1, int* fdefined, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  enter(c);
+  if (op != MIFC_OP_ADVECTION && op != MIFC_OP_TFP && op != MIFC_OP_QVECTOR && op != MIFC_OP_SHAPIRO2)
+    return mifc_stencil_levels(c, op, nx, ny, nlev, f0, f1, xmapr, ymapr, fcoriolis, out0, out1, fdefined, undef, memkind);
+  if (nx < 3 || ny < 3 || nlev < 1 || !f0 || !out0 || !fdefined)
+    return 0;
+  if (op == MIFC_OP_ADVECTION) { // FieldCalculations.cc:1942-1983: f0 = f, f1 = u, f2 = v, scalar = hours
+    if (!f1 || !f2)
+      return 0;
+    StencilCall sc = {mifc::ST_ADVECTION, nx, ny, nlev, f0, f1, xmapr, ymapr, nullptr, out0, nullptr};
+    sc.f2 = f2;
+    sc.scale = (float)(-3600. * (double)scalar); // :1963
+    return run_stencil(c, sc, fdefined, undef, memkind);
+  }
+  const size_t n = (size_t)nx * ny, nb = n * (size_t)nlev;
+  std::vector<float> tscale, cscale;
+  if (op == MIFC_OP_QVECTOR) { // :526-540, per level like the single-field call
+    if (!f1 || !fcoriolis || !level_scalars)
+      return 0;
+    tscale.resize(nlev);
+    cscale.resize(nlev);
+    for (int l = 0; l < nlev; ++l) {
+      const float p = level_scalars[l];
+      if (p <= 0.0)
+        return 0;
+      if (compute == 1 || compute == 3)
+        tscale[l] = 1.0f;
+      else if (compute == 2 || compute == 4)
+        tscale[l] = K_CP * powf(p / 1000.0f, 287.f / K_CP) / K_CP; // :539, host powf like the reference
+      else
+        return 0;
+      cscale[l] = (float)((double)(-287.f) / ((double)p * 100.)); // :564
+    }
+  }
+  bool ok = true;
+  const float* d0 = stage_in(c, 0, f0, nb, memkind, &ok);
+  const float* d1 = (op == MIFC_OP_QVECTOR) ? stage_in(c, 1, f1, nb, memkind, &ok) : nullptr;
+  const float* dxm = (op != MIFC_OP_SHAPIRO2) ? stage_in(c, 2, xmapr, n, memkind, &ok) : nullptr;
+  const float* dym = (op != MIFC_OP_SHAPIRO2) ? stage_in(c, 3, ymapr, n, memkind, &ok) : nullptr;
+  const float* dfc = (op == MIFC_OP_QVECTOR) ? stage_in(c, 4, fcoriolis, n, memkind, &ok) : nullptr;
+  float* dout = stage_out(c, 5, out0, nb, memkind, &ok);
+  if (!ok || !ensure_levels(c, (size_t)nlev))
+    return 0;
+  if (op != MIFC_OP_SHAPIRO2 && (!dxm || !dym))
+    return 0;
+  // the levels in two groups: ALL_DEFINED input first
+  std::vector<int> order;
+  order.reserve(nlev);
+  for (int l = 0; l < nlev; ++l)
+    if (fdefined[l] == MIFC_ALL_DEFINED)
+      order.push_back(l);
+  const int n_all = (int)order.size();
+  for (int l = 0; l < nlev; ++l)
+    if (fdefined[l] != MIFC_ALL_DEFINED)
+      order.push_back(l);
+  bool fused = nlev <= 65535;
+  if (op == MIFC_OP_SHAPIRO2) {
+    float* dst = dout;
+    if (dout == d0) { // in place (allowed by the reference, :2088): through a scratch batch
+      if (!ensure_slot(c, 8, nb * sizeof(float)))
+        return 0;
+      dst = static_cast<float*>(c->slot[8]);
+    }
+    fused = fused && mifc::env().shapiro_fused && mifc::shapiro2_fused_supported(nx, ny, d0, dst) && n % 4 == 0;
+    if (fused) {
+      MIFC_HIP(c, hipMemcpyAsync(c->d_levels, order.data(), sizeof(int) * (size_t)nlev, hipMemcpyHostToDevice, c->stream));
+      if (n_all > 0)
+        MIFC_LAUNCH(c, mifc::launch_shapiro2_fused_levels(nx, ny, 1, undef, d0, dst, n_all, (long)n, c->d_levels, c->stream));
+      if (nlev - n_all > 0)
+        MIFC_LAUNCH(c, mifc::launch_shapiro2_fused_levels(nx, ny, 0, undef, d0, dst, nlev - n_all, (long)n, c->d_levels + n_all, c->stream));
+      if (dst != dout)
+        MIFC_HIP(c, hipMemcpyAsync(dout, dst, nb * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      if (!fetch_out(c, 5, out0, nb, memkind))
+        return 0;
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+      for (int l = 0; l < nlev; ++l)
+        fdefined[l] = MIFC_ALL_DEFINED; // :2171
+      return 1;
+    }
+  } else {
+    mifc::Fused2Params F;
+    std::memset(&F, 0, sizeof F);
+    F.op = (op == MIFC_OP_TFP) ? mifc::F2_TFP : (compute < 3 ? mifc::F2_QVEC_X : mifc::F2_QVEC_Y);
+    F.nx = nx;
+    F.ny = ny;
+    F.a = d0;
+    F.t = d1;
+    F.xmapr = dxm;
+    F.ymapr = dym;
+    F.fcoriolis = dfc;
+    F.out = dout;
+    F.undef = undef;
+    F.counts = c->d_counts;
+    F.level_stride = (long)n;
+    fused = fused && fused2_enabled() && mifc::fused2_supported(F) && n % 4 == 0 && 3 * (size_t)nlev <= 4 * c->cap_lev;
+    if (fused) {
+      if (!pinned_acquire(c))
+        return 0;
+      MIFC_HIP(c, hipMemcpyAsync(c->d_levels, order.data(), sizeof(int) * (size_t)nlev, hipMemcpyHostToDevice, c->stream));
+      if (op == MIFC_OP_QVECTOR) {
+        MIFC_HIP(c, hipMemcpyAsync(c->d_ab, tscale.data(), sizeof(float) * (size_t)nlev, hipMemcpyHostToDevice, c->stream));
+        MIFC_HIP(c, hipMemcpyAsync(c->d_ab + c->cap_lev, cscale.data(), sizeof(float) * (size_t)nlev, hipMemcpyHostToDevice, c->stream));
+        F.scale_lev = c->d_ab;
+        F.scale2_lev = c->d_ab + c->cap_lev;
+      }
+      MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, 3 * sizeof(u64) * (size_t)nlev, c->stream));
+      for (int group = 0; group < 2; ++group) {
+        const int first = group == 0 ? 0 : n_all, count = group == 0 ? n_all : nlev - n_all;
+        if (count == 0)
+          continue;
+        F.check = group;
+        F.n_launch_levels = count;
+        F.levels = c->d_levels + first;
+        MIFC_LAUNCH(c, mifc::launch_fused2(F, c->stream));
+      }
+      MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, 3 * sizeof(u64) * (size_t)nlev, hipMemcpyDeviceToHost, c->stream));
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+      const u64* cnt = pinned_counts(c);
+      std::vector<int> redo;
+      for (int l = 0; l < nlev; ++l) {
+        const u64* k = cnt + 3 * (size_t)l;
+        // thermalFrontParameter: the second pass is tested only if the first left something undefined (:2286); see run_fused2()
+        if (op == MIFC_OP_TFP && fdefined[l] != MIFC_ALL_DEFINED && k[0] == 0 && k[2] != 0)
+          redo.push_back(l);
+        else
+          fdefined[l] = mifc_classify(k[1], (u64)n - 2 * (u64)nx); // :2303, :590
+      }
+      for (int l : redo) // rare: those levels again, pass by pass
+        if (!tfp_two_passes(c, nx, ny, d0 + (size_t)l * n, dxm, dym, dout + (size_t)l * n, fdefined + l, undef))
+          return 0;
+      if (!fetch_out(c, 5, out0, nb, memkind))
+        return 0;
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+      return 1;
+    }
+  }
+  // level by level on the staged (device) batch
+  if (!f1_levels_fallback(c, op, nx, ny, nlev, d0, d1, dxm, dym, dfc, level_scalars, compute, dout, fdefined, undef))
+    return 0;
+  if (!fetch_out(c, 5, out0, nb, memkind))
+    return 0;
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  return 1;
+}
+
 int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
                                 float* rvort, float* diverg, const int* fdefined_in, float undef, unsigned long long* n_undefined_dev)
 {
@@ -1291,45 +1480,98 @@ int mifc_vortdiv_levels_strided_enqueue(mifc_ctx* c, int nx, int ny, int nlev, c
   return 1;
 }
 
-static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q, const float* ps,
-                          const float* alevel, const float* blevel, float* ff, float* rh, float* theta, const int* fdef_wind, const int* fdef_thermo,
-                          float undef, u64* counts_dev, bool* every_all_out, mifc::DerivedParams* prepared_only = nullptr)
+} // extern "C"
+
+// ---- fused derived variables on hybrid levels --------------------------------
+namespace {
+
+struct DerivedRequest
+{
+  const float *u, *v, *t, *h, *ps;
+  const float *alevel, *blevel;
+  float *ff, *temp, *hum, *hum2;
+  const char *temp_unit, *hum_unit, *hum2_unit;
+  int temp_compute, hum_compute, hum2_compute;
+};
+
+// hlevelhum's remaps (:1168-1182) for one humidity output; false = the reference returns false
+bool derived_hum_variant(const char* unit, int compute, int* code, float* tdconv)
+{
+  if (compute <= 0 || compute >= 13) // :1168
+    return false;
+  if (compute > 8 && unit_is(unit, "celsius")) // :1174-1177
+    compute -= 4;
+  else if (compute > 4 && compute <= 8 && unit_is(unit, "kelvin"))
+    compute += 4;
+  *tdconv = (compute >= 9) ? K_T0 : 0; // :1181
+  *code = 1 + hum_kind_ah(compute) + 4 * ((compute % 2 == 0) ? 1 : 0);
+  return true;
+}
+
+// Validates like the per-level reference calls would, uploads the per-level scalars and launches (or,
+// with prepared_only, hands the parameters to the host pipeline).  counts_dev: u64[4 * nlev], ff | temp | hum | hum2.
+int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq, const int* fdef_wind, const int* fdef_thermo, float undef,
+                   u64* counts_dev, mifc::DerivedParams* prepared_only = nullptr)
 {
   if (nlev < 1 || nx * ny <= 0)
     return 0;
-  if (!ff && !rh && !theta)
+  if (!rq.ff && !rq.temp && !rq.hum && !rq.hum2)
     return 0;
-  if (rh || theta) {
+  const bool thermo = rq.temp || rq.hum || rq.hum2;
+  mifc::DerivedParams P;
+  std::memset(&P, 0, sizeof P);
+  if (rq.temp) {
+    int compute = rq.temp_compute;
+    if (compute < 3) { // :1060-1065
+      if (unit_is(rq.temp_unit, "celsius"))
+        compute = 1;
+      else if (unit_is(rq.temp_unit, "kelvin"))
+        compute = 2;
+    }
+    if (compute < 1 || compute > 5) { // the reference leaves such cells unwritten (:1080-1090): not offered in the batched form
+      c->err = "mifc_hlevel_derived_batch: temp_compute must be 1..5";
+      return 0;
+    }
+    P.temp_compute = compute;
+  }
+  if (rq.hum && !derived_hum_variant(rq.hum_unit, rq.hum_compute, &P.hum_code, &P.hum_tdconv))
+    return 0;
+  if (rq.hum2 && !derived_hum_variant(rq.hum2_unit, rq.hum2_compute, &P.td_code, &P.td_tdconv))
+    return 0;
+  if (thermo) {
     for (int l = 0; l < nlev; ++l)
-      if (bad_hlevel(alevel[l], blevel[l])) // :1070, :1170
+      if (bad_hlevel(rq.alevel[l], rq.blevel[l])) // :1070, :1170
         return 0;
   }
   if (!ensure_levels(c, (size_t)nlev))
     return 0;
-  mifc::DerivedParams P;
-  std::memset(&P, 0, sizeof P);
   P.n = nx * ny;
   P.nlev = nlev;
-  P.u = u;
-  P.v = v;
-  P.t = t;
-  P.q = q;
-  P.ps = ps;
-  P.ff = ff;
-  P.rh = rh;
-  P.theta = theta;
+  P.u = rq.u;
+  P.v = rq.v;
+  P.t = rq.t;
+  P.h = rq.h;
+  P.ps = rq.ps;
+  P.ff = rq.ff;
+  P.temp = rq.temp;
+  P.hum = rq.hum;
+  P.td = rq.hum2;
   P.undef = undef;
+  P.cnt_ff = counts_dev;
+  P.cnt_temp = counts_dev + nlev;
+  P.cnt_hum = counts_dev + 2 * (size_t)nlev;
+  P.cnt_td = counts_dev + 3 * (size_t)nlev;
   bool every_all = true;
   if (nlev <= 8 && !prepared_only) {
     // small batch: per-level scalars travel in the kernel arguments
     P.n_inline = 1;
     for (int l = 0; l < nlev; ++l) {
-      const bool w = !ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
-      const bool th = !(rh || theta) || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
+      const bool w = !rq.ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
+      const bool th = !thermo || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
       P.wind_inline[l] = w ? 1 : 0;
       P.thermo_inline[l] = th ? 1 : 0;
-      P.a_inline[l] = (rh || theta) ? alevel[l] : 0.f;
-      P.b_inline[l] = (rh || theta) ? blevel[l] : 0.f;
+      P.a_inline[l] = thermo ? rq.alevel[l] : 0.f;
+      P.b_inline[l] = thermo ? rq.blevel[l] : 0.f;
       every_all = every_all && w && th;
     }
   } else {
@@ -1337,16 +1579,16 @@ static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u,
       return 0;
     unsigned char* hf = pinned_flags(c);
     for (int l = 0; l < nlev; ++l) {
-      const bool w = !ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
-      const bool th = !(rh || theta) || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
+      const bool w = !rq.ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
+      const bool th = !thermo || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
       hf[l] = w ? 1 : 0;
       hf[c->cap_lev + l] = th ? 1 : 0;
       every_all = every_all && w && th;
     }
     float* hab = pinned_ab(c);
     for (int l = 0; l < nlev; ++l) {
-      hab[l] = (rh || theta) ? alevel[l] : 0.f;
-      hab[c->cap_lev + l] = (rh || theta) ? blevel[l] : 0.f;
+      hab[l] = thermo ? rq.alevel[l] : 0.f;
+      hab[c->cap_lev + l] = thermo ? rq.blevel[l] : 0.f;
     }
     MIFC_HIP(c, hipMemcpyAsync(c->d_ab, hab, 2 * c->cap_lev * sizeof(float), hipMemcpyHostToDevice, c->stream));
     MIFC_HIP(c, hipMemcpyAsync(c->d_flags, hf, 2 * c->cap_lev, hipMemcpyHostToDevice, c->stream));
@@ -1358,20 +1600,164 @@ static int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const float* u,
     P.thermo_all_defined = c->d_flags + c->cap_lev;
   }
   P.every_level_all_defined = every_all ? 1 : 0;
-  P.n_undefined = counts_dev;
-  MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 3 * sizeof(u64) * (size_t)nlev, c->stream));
-  if (prepared_only) // the caller launches chunk by chunk (host pipeline)
+  MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 4 * sizeof(u64) * (size_t)nlev, c->stream));
+  if (prepared_only) { // the caller launches chunk by chunk (host pipeline)
     *prepared_only = P;
-  else {
+  } else {
     MIFC_LAUNCH(c, mifc::launch_derived_levels(P, c->stream));
     if (!P.n_inline && !scratch_release(c)) // the kernel reads c->d_flags and c->d_ab
       return 0;
   }
-  if (every_all_out)
-    *every_all_out = every_all;
   return 1;
 }
 
+void derived_flags(const u64* cnt, int nlev, size_t n, const DerivedRequest& rq, int* fdef_ff, int* fdef_temp, int* fdef_hum, int* fdef_hum2)
+{
+  for (int l = 0; l < nlev; ++l) {
+    if (rq.ff && fdef_ff)
+      fdef_ff[l] = mifc_classify(cnt[l], (u64)n);
+    if (rq.temp && fdef_temp)
+      fdef_temp[l] = mifc_classify(cnt[nlev + l], (u64)n);
+    if (rq.hum && fdef_hum)
+      fdef_hum[l] = mifc_classify(cnt[2 * (size_t)nlev + l], (u64)n);
+    if (rq.hum2 && fdef_hum2)
+      fdef_hum2[l] = mifc_classify(cnt[3 * (size_t)nlev + l], (u64)n);
+  }
+}
+
+int derived_sync(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq0, const int* fdef_wind, const int* fdef_thermo, int* fdef_ff,
+                 int* fdef_temp, int* fdef_hum, int* fdef_hum2, float undef, int memkind)
+{
+  if (nlev < 1 || nx * ny <= 0)
+    return 0;
+  if ((nx * ny) % 4 != 0) {
+    c->err = "mifc_hlevel_derived_batch: nx*ny must be a multiple of 4 (use the per-field operators otherwise)";
+    return 0;
+  }
+  const size_t n = (size_t)nx * ny, nb = n * (size_t)nlev;
+  const bool thermo = rq0.temp || rq0.hum || rq0.hum2;
+  const bool humid = rq0.hum || rq0.hum2;
+  DerivedRequest rq = rq0;
+  bool ok = true;
+  if (memkind == MIFC_MEM_HOST && mifc::hostpipe_chunk_levels(n, nlev) > 0 && host_pipeline_enabled()) {
+    // a large batch in host memory: chunks of levels stream through the device, copies
+    // in both directions overlapping the kernels (mifc_hostpipe.h)
+    if (!c->pipe && !(c->pipe = mifc::hostpipe_create(c->device))) {
+      c->err = "host pipeline: cannot create streams";
+      return 0;
+    }
+    rq.ps = thermo ? stage_in(c, 4, rq0.ps, n, memkind, &ok) : nullptr;
+    if (!ok || !ensure_levels(c, (size_t)nlev))
+      return 0;
+    mifc::DerivedParams base;
+    // the host pointers are placeholders that mark which fields take part; the chunk launcher substitutes device buffers
+    rq.u = rq0.ff ? rq0.u : nullptr;
+    rq.v = rq0.ff ? rq0.v : nullptr;
+    rq.t = thermo ? rq0.t : nullptr;
+    rq.h = humid ? rq0.h : nullptr;
+    if (!derived_common(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, undef, c->d_counts, &base))
+      return 0;
+    MIFC_HIP(c, hipStreamSynchronize(c->stream)); // ps, flags, level coefficients, zeroed counters are in place
+    const float* h_in[4];
+    int slot_u = -1, slot_v = -1, slot_t = -1, slot_h = -1, n_in = 0;
+    if (rq0.ff) {
+      slot_u = n_in;
+      h_in[n_in++] = rq0.u;
+      slot_v = n_in;
+      h_in[n_in++] = rq0.v;
+    }
+    if (thermo) {
+      slot_t = n_in;
+      h_in[n_in++] = rq0.t;
+    }
+    if (humid) {
+      slot_h = n_in;
+      h_in[n_in++] = rq0.h;
+    }
+    float* h_out[4] = {rq0.ff, rq0.temp, rq0.hum, rq0.hum2};
+    const mifc::ChunkLaunch launch = [&](int l0, int nl, const float* const* d_in, float* const* d_out, hipStream_t stream) {
+      mifc::DerivedParams p = base;
+      p.nlev = nl;
+      p.u = slot_u >= 0 ? d_in[slot_u] : nullptr;
+      p.v = slot_v >= 0 ? d_in[slot_v] : nullptr;
+      p.t = slot_t >= 0 ? d_in[slot_t] : nullptr;
+      p.h = slot_h >= 0 ? d_in[slot_h] : nullptr;
+      p.ff = d_out[0];
+      p.temp = d_out[1];
+      p.hum = d_out[2];
+      p.td = d_out[3];
+      p.alevel = base.alevel + l0;
+      p.blevel = base.blevel + l0;
+      p.wind_all_defined = base.wind_all_defined + l0;
+      p.thermo_all_defined = base.thermo_all_defined + l0;
+      p.cnt_ff = base.cnt_ff + l0;
+      p.cnt_temp = base.cnt_temp + l0;
+      p.cnt_hum = base.cnt_hum + l0;
+      p.cnt_td = base.cnt_td + l0;
+      return mifc::launch_derived_levels(p, stream);
+    };
+    if (!mifc::hostpipe_run(c->pipe, n, nlev, n_in, h_in, 4, h_out, launch, &c->err))
+      return 0;
+  } else {
+    rq.u = rq0.ff ? stage_in(c, 0, rq0.u, nb, memkind, &ok) : nullptr;
+    rq.v = rq0.ff ? stage_in(c, 1, rq0.v, nb, memkind, &ok) : nullptr;
+    rq.t = thermo ? stage_in(c, 2, rq0.t, nb, memkind, &ok) : nullptr;
+    rq.h = humid ? stage_in(c, 3, rq0.h, nb, memkind, &ok) : nullptr;
+    rq.ps = thermo ? stage_in(c, 4, rq0.ps, n, memkind, &ok) : nullptr;
+    rq.ff = stage_out(c, 5, rq0.ff, nb, memkind, &ok);
+    rq.temp = stage_out(c, 6, rq0.temp, nb, memkind, &ok);
+    rq.hum = stage_out(c, 7, rq0.hum, nb, memkind, &ok);
+    rq.hum2 = stage_out(c, 8, rq0.hum2, nb, memkind, &ok);
+    if (!ok || !ensure_levels(c, (size_t)nlev))
+      return 0;
+    if (!derived_common(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, undef, c->d_counts))
+      return 0;
+    if (!fetch_out(c, 5, rq0.ff, nb, memkind) || !fetch_out(c, 6, rq0.temp, nb, memkind) || !fetch_out(c, 7, rq0.hum, nb, memkind) ||
+        !fetch_out(c, 8, rq0.hum2, nb, memkind))
+      return 0;
+  }
+  MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, 4 * sizeof(u64) * (size_t)nlev, hipMemcpyDeviceToHost, c->stream));
+  MIFC_HIP(c, hipStreamSynchronize(c->stream));
+  derived_flags(pinned_counts(c), nlev, n, rq0, fdef_ff, fdef_temp, fdef_hum, fdef_hum2);
+  return 1;
+}
+
+} // namespace
+
+extern "C" {
+
+int mifc_hlevel_derived_batch(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* h, const float* ps,
+                              const float* alevel, const float* blevel, float* ff, float* temp, const char* temp_unit, int temp_compute, float* hum,
+                              const char* hum_unit, int hum_compute, float* hum2, const char* hum2_unit, int hum2_compute, const int* fdef_wind,
+                              const int* fdef_thermo, int* fdef_ff, int* fdef_temp, int* fdef_hum, int* fdef_hum2, float undef, int memkind)
+{
+  if (!c)
+    return 0;
+  enter(c);
+  const DerivedRequest rq = {u, v, t, h, ps, alevel, blevel, ff, temp, hum, hum2, temp_unit, hum_unit, hum2_unit, temp_compute, hum_compute, hum2_compute};
+  return derived_sync(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, fdef_ff, fdef_temp, fdef_hum, fdef_hum2, undef, memkind);
+}
+
+int mifc_hlevel_derived_batch_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* h,
+                                      const float* ps, const float* alevel, const float* blevel, float* ff, float* temp, const char* temp_unit,
+                                      int temp_compute, float* hum, const char* hum_unit, int hum_compute, float* hum2, const char* hum2_unit,
+                                      int hum2_compute, const int* fdef_wind, const int* fdef_thermo, float undef,
+                                      unsigned long long* n_undefined_dev)
+{
+  if (!c || !n_undefined_dev)
+    return 0;
+  enter(c);
+  if ((nx * ny) % 4 != 0) {
+    c->err = "mifc_hlevel_derived_batch: nx*ny must be a multiple of 4 (use the per-field operators otherwise)";
+    return 0;
+  }
+  const DerivedRequest rq = {u, v, t, h, ps, alevel, blevel, ff, temp, hum, hum2, temp_unit, hum_unit, hum2_unit, temp_compute, hum_compute, hum2_compute};
+  return derived_common(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, undef, n_undefined_dev);
+}
+
+// The original trio: ff, RH (hlevelhum compute 1), theta (hleveltemp compute 3).  n_undefined_dev keeps its
+// documented layout u64[3 * nlev] = ff | rh | theta: the counters are collected in the context's own
+// 4-array scratch and copied out in that order on the stream.
 int mifc_hlevel_derived_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q,
                                        const float* ps, const float* alevel, const float* blevel, float* ff, float* rh, float* theta,
                                        const int* fdef_wind, const int* fdef_thermo, float undef, unsigned long long* n_undefined_dev)
@@ -1383,7 +1769,16 @@ int mifc_hlevel_derived_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, co
     c->err = "mifc_hlevel_derived_levels: nx*ny must be a multiple of 4 (use the per-field operators otherwise)";
     return 0;
   }
-  return derived_common(c, nx, ny, nlev, u, v, t, q, ps, alevel, blevel, ff, rh, theta, fdef_wind, fdef_thermo, undef, n_undefined_dev, nullptr);
+  if (nlev < 1 || !ensure_levels(c, (size_t)nlev))
+    return 0;
+  const DerivedRequest rq = {u, v, t, q, ps, alevel, blevel, ff, theta, rh, nullptr, "", "", "", 3, 1, 0};
+  if (!derived_common(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, undef, c->d_counts))
+    return 0;
+  const size_t row = sizeof(u64) * (size_t)nlev;
+  MIFC_HIP(c, hipMemcpyAsync(n_undefined_dev, c->d_counts, row, hipMemcpyDeviceToDevice, c->stream));                      // ff
+  MIFC_HIP(c, hipMemcpyAsync(n_undefined_dev + nlev, c->d_counts + 2 * (size_t)nlev, row, hipMemcpyDeviceToDevice, c->stream)); // rh  <- hum
+  MIFC_HIP(c, hipMemcpyAsync(n_undefined_dev + 2 * (size_t)nlev, c->d_counts + nlev, row, hipMemcpyDeviceToDevice, c->stream)); // theta <- temp
+  return scratch_release(c) ? 1 : 0; // the copies read c->d_counts
 }
 
 int mifc_hlevel_derived_levels(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* q, const float* ps,
@@ -1393,106 +1788,8 @@ int mifc_hlevel_derived_levels(mifc_ctx* c, int nx, int ny, int nlev, const floa
   if (!c)
     return 0;
   enter(c);
-  if (nlev < 1 || nx * ny <= 0)
-    return 0;
-  if ((nx * ny) % 4 != 0) {
-    c->err = "mifc_hlevel_derived_levels: nx*ny must be a multiple of 4 (use the per-field operators otherwise)";
-    return 0;
-  }
-  const size_t n = (size_t)nx * ny, nb = n * (size_t)nlev;
-  bool ok = true;
-  if (memkind == MIFC_MEM_HOST && mifc::hostpipe_chunk_levels(n, nlev) > 0 && host_pipeline_enabled()) {
-    // a large batch in host memory: chunks of levels stream through the device, copies
-    // in both directions overlapping the kernels (mifc_hostpipe.h)
-    if (!c->pipe && !(c->pipe = mifc::hostpipe_create(c->device))) {
-      c->err = "host pipeline: cannot create streams";
-      return 0;
-    }
-    const float* dps = (rh || theta) ? stage_in(c, 4, ps, n, memkind, &ok) : nullptr;
-    if (!ok || !ensure_levels(c, (size_t)nlev))
-      return 0;
-    mifc::DerivedParams base;
-    // placeholders mark which fields take part; the chunk launcher substitutes device buffers
-    if (!derived_common(c, nx, ny, nlev, ff ? u : nullptr, ff ? v : nullptr, (rh || theta) ? t : nullptr, rh ? q : nullptr, dps, alevel, blevel, ff, rh,
-                        theta, fdef_wind, fdef_thermo, undef, c->d_counts, nullptr, &base))
-      return 0;
-    MIFC_HIP(c, hipStreamSynchronize(c->stream)); // ps, flags, level coefficients, zeroed counters are in place
-    const float* h_in[4];
-    int slot_u = -1, slot_v = -1, slot_t = -1, slot_q = -1, n_in = 0;
-    if (ff) {
-      slot_u = n_in;
-      h_in[n_in++] = u;
-      slot_v = n_in;
-      h_in[n_in++] = v;
-    }
-    if (rh || theta) {
-      slot_t = n_in;
-      h_in[n_in++] = t;
-    }
-    if (rh) {
-      slot_q = n_in;
-      h_in[n_in++] = q;
-    }
-    float* h_out[3] = {ff, rh, theta};
-    const mifc::ChunkLaunch launch = [&](int l0, int nl, const float* const* d_in, float* const* d_out, hipStream_t stream) {
-      mifc::DerivedParams p = base;
-      p.nlev = nl;
-      p.count_stride = nlev;
-      p.u = slot_u >= 0 ? d_in[slot_u] : nullptr;
-      p.v = slot_v >= 0 ? d_in[slot_v] : nullptr;
-      p.t = slot_t >= 0 ? d_in[slot_t] : nullptr;
-      p.q = slot_q >= 0 ? d_in[slot_q] : nullptr;
-      p.ff = d_out[0];
-      p.rh = d_out[1];
-      p.theta = d_out[2];
-      p.alevel = base.alevel + l0;
-      p.blevel = base.blevel + l0;
-      p.wind_all_defined = base.wind_all_defined + l0;
-      p.thermo_all_defined = base.thermo_all_defined + l0;
-      p.n_undefined = base.n_undefined + l0;
-      return mifc::launch_derived_levels(p, stream);
-    };
-    if (!mifc::hostpipe_run(c->pipe, n, nlev, n_in, h_in, 3, h_out, launch, &c->err))
-      return 0;
-    MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, 3 * sizeof(u64) * (size_t)nlev, hipMemcpyDeviceToHost, c->stream));
-    MIFC_HIP(c, hipStreamSynchronize(c->stream));
-    const u64* cnt = pinned_counts(c);
-    for (int l = 0; l < nlev; ++l) {
-      if (ff && fdef_ff)
-        fdef_ff[l] = mifc_classify(cnt[l], (u64)n);
-      if (rh && fdef_rh)
-        fdef_rh[l] = mifc_classify(cnt[nlev + l], (u64)n);
-      if (theta && fdef_theta)
-        fdef_theta[l] = mifc_classify(cnt[2 * nlev + l], (u64)n);
-    }
-    return 1;
-  }
-  const float* du = ff ? stage_in(c, 0, u, nb, memkind, &ok) : nullptr;
-  const float* dv = ff ? stage_in(c, 1, v, nb, memkind, &ok) : nullptr;
-  const float* dt = (rh || theta) ? stage_in(c, 2, t, nb, memkind, &ok) : nullptr;
-  const float* dq = rh ? stage_in(c, 3, q, nb, memkind, &ok) : nullptr;
-  const float* dps = (rh || theta) ? stage_in(c, 4, ps, n, memkind, &ok) : nullptr;
-  float* dff = stage_out(c, 5, ff, nb, memkind, &ok);
-  float* drh = stage_out(c, 6, rh, nb, memkind, &ok);
-  float* dth = stage_out(c, 7, theta, nb, memkind, &ok);
-  if (!ok || !ensure_levels(c, (size_t)nlev))
-    return 0;
-  if (!derived_common(c, nx, ny, nlev, du, dv, dt, dq, dps, alevel, blevel, dff, drh, dth, fdef_wind, fdef_thermo, undef, c->d_counts, nullptr))
-    return 0;
-  MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, 3 * sizeof(u64) * (size_t)nlev, hipMemcpyDeviceToHost, c->stream));
-  if (!fetch_out(c, 5, ff, nb, memkind) || !fetch_out(c, 6, rh, nb, memkind) || !fetch_out(c, 7, theta, nb, memkind))
-    return 0;
-  MIFC_HIP(c, hipStreamSynchronize(c->stream));
-  const u64* cnt = pinned_counts(c);
-  for (int l = 0; l < nlev; ++l) {
-    if (ff && fdef_ff)
-      fdef_ff[l] = mifc_classify(cnt[l], (u64)n);
-    if (rh && fdef_rh)
-      fdef_rh[l] = mifc_classify(cnt[nlev + l], (u64)n);
-    if (theta && fdef_theta)
-      fdef_theta[l] = mifc_classify(cnt[2 * nlev + l], (u64)n);
-  }
-  return 1;
+  const DerivedRequest rq = {u, v, t, q, ps, alevel, blevel, ff, theta, rh, nullptr, "", "", "", 3, 1, 0};
+  return derived_sync(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, fdef_ff, fdef_theta, fdef_rh, nullptr, undef, memkind);
 }
 
 int mifc_vortdiv_slab_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny_local, const float* u_halo, const float* v_halo, const float* xmapr,

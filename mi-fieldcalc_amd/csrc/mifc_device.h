@@ -234,6 +234,29 @@ __device__ __forceinline__ float pidcp_of(const PowTables& T, float p)
   return pow_kappa(T, p * MIFC_K_P0INV);
 }
 
+// ---- two double quotients with one denominator
+// The compiler expands a / b (f64) into v_div_scale x2, v_rcp_f64, four Newton fmas, then
+// q = a*y, r = fma(-b, q, a), v_div_fmas(r, y, q), v_div_fixup (LLVM AMDGPU LowerFDIV64).
+// v_div_scale only rescales operands near the ends of the double range (denormal b, 1/b or
+// a/b, |a| < 2^-969, exponents >= 768 apart); values converted from float, and products of
+// two or three of them, never get there, so for those the sequence below IS that expansion,
+// bit for bit -- and quotients that share b share the v_rcp_f64 and the four fmas.
+// Zero, infinite and NaN operands are settled by v_div_fixup as in the expansion.
+__device__ __forceinline__ double shared_reciprocal(double b)
+{
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double quotient(double a, double b, double y /* shared_reciprocal(b) */)
+{
+  const double q = a * y;
+  const double r = __builtin_fma(-b, q, a);
+  return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q), b, a);
+}
+
 // The point functions return false where the table does not cover tk
 // (reference: cell := undef, n_undefined += 1).
 // FieldCalculations.cc:196-205
@@ -263,7 +286,10 @@ __device__ __forceinline__ bool tk_q_rh(const float* tab, float tk, float q, flo
   if (!e.ok())
     return false;
   const float qsat = MIFC_K_EPS * e.value(tab) / p;
-  out = (float)(100. * (double)q / (double)qsat);
+  // 100. * q / qsat in double: the division through the refined reciprocal -- for float-born operands it IS the
+  // f64 division, bit for bit (see shared_reciprocal above; mifc_diag_division checks it), three instructions shorter
+  const double d = (double)qsat;
+  out = (float)quotient(100. * (double)q, d, shared_reciprocal(d));
   return true;
 }
 // FieldCalculations.cc:229-238
@@ -337,29 +363,6 @@ __device__ __forceinline__ float f_diverg(float xm, float ym, float dudx, float 
   return (float)__builtin_fma(0.5 * (double)xm, (double)dudx, 0.5 * (double)ym * (double)dvdy);
 }
 #endif
-
-// ---- two double quotients with one denominator
-// The compiler expands a / b (f64) into v_div_scale x2, v_rcp_f64, four Newton fmas, then
-// q = a*y, r = fma(-b, q, a), v_div_fmas(r, y, q), v_div_fixup (LLVM AMDGPU LowerFDIV64).
-// v_div_scale only rescales operands near the ends of the double range (denormal b, 1/b or
-// a/b, |a| < 2^-969, exponents >= 768 apart); values converted from float, and products of
-// two or three of them, never get there, so for those the sequence below IS that expansion,
-// bit for bit -- and quotients that share b share the v_rcp_f64 and the four fmas.
-// Zero, infinite and NaN operands are settled by v_div_fixup as in the expansion.
-__device__ __forceinline__ double shared_reciprocal(double b)
-{
-  double y = __builtin_amdgcn_rcp(b);
-  double e = __builtin_fma(-b, y, 1.0);
-  y = __builtin_fma(y, e, y);
-  e = __builtin_fma(-b, y, 1.0);
-  return __builtin_fma(y, e, y);
-}
-__device__ __forceinline__ double quotient(double a, double b, double y /* shared_reciprocal(b) */)
-{
-  const double q = a * y;
-  const double r = __builtin_fma(-b, q, a);
-  return __builtin_amdgcn_div_fixup(__builtin_fma(r, y, q), b, a);
-}
 
 // ---- undefined-cell counting: one atomic per wave, none when nothing to add
 __device__ __forceinline__ void wave_count_add(u64* counter, unsigned int my_count)

@@ -318,135 +318,6 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
   }
 }
 
-// ----------------------------------------------------------------------------
-// Fused (ff, rh, theta) over hybrid model levels -- BASELINE.json config 2.
-//   ff    = vectorabs(u,v)                      12 B/cell alone
-//   rh    = hlevelhum compute 1  (T,q,ps -> RH %)
-//   theta = hleveltemp compute 3 (T,ps -> theta)
-// Fused traffic: u,v,t,q read once (16 B), ps re-read per level from L2/MALL,
-// three outputs (12 B)  => 28 B/cell + ps.  p = a + b*ps and powf(p*p0inv,
-// kappa) are evaluated once per cell and shared by rh (needs p) and theta
-// (needs pidcp).  grid.y = level; each lane owns 4 consecutive cells.
-template <bool CHECK>
-__global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams P)
-{
-  __shared__ float s_ewt[MIFC_EWT_LDS];
-  __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
-  ewt_table_init(s_ewt);
-  const PowTables PT = pow_tables_init(s_pow);
-
-  const int lev = blockIdx.y;
-  const size_t base = (size_t)lev * (size_t)P.n;
-  const bool want_ff = P.ff != nullptr, want_rh = P.rh != nullptr, want_th = P.theta != nullptr;
-  const bool wind_all = CHECK ? ((P.n_inline ? P.wind_inline[lev] : P.wind_all_defined[lev]) != 0) : true;
-  const bool thermo_all = CHECK ? ((P.n_inline ? P.thermo_inline[lev] : P.thermo_all_defined[lev]) != 0) : true;
-  const float a = P.n_inline ? P.a_inline[lev] : P.alevel[lev];
-  const float b = P.n_inline ? P.b_inline[lev] : P.blevel[lev];
-  const float undef = P.undef;
-  unsigned int bad_ff = 0, bad_rh = 0, bad_th = 0;
-
-  const int n4 = P.n >> 2;
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += gridDim.x * blockDim.x) {
-    const size_t o = base + (size_t)q * 4;
-    if (want_ff) {
-      const float4 u4 = *reinterpret_cast<const float4*>(P.u + o);
-      const float4 v4 = *reinterpret_cast<const float4*>(P.v + o);
-      const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
-      float r[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (wind_all || (is_def(uu[k], undef) && is_def(vv[k], undef))) {
-          r[k] = absval(uu[k], vv[k]);
-        } else {
-          r[k] = undef;
-          bad_ff += 1;
-        }
-      }
-      store4_stream(P.ff + o, r[0], r[1], r[2], r[3]);
-    }
-    if (want_rh || want_th) {
-      const float4 t4 = *reinterpret_cast<const float4*>(P.t + o);
-      const float4 s4 = *reinterpret_cast<const float4*>(P.ps + (size_t)q * 4);
-      const float4 q4 = want_rh ? *reinterpret_cast<const float4*>(P.q + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float tt[4] = {t4.x, t4.y, t4.z, t4.w}, ss[4] = {s4.x, s4.y, s4.z, s4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
-      float rr[4], rt[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float p = a + b * ss[k]; // p_hlevel :303
-        if (want_th) {              // hleveltemp compute 3, :1077-1085
-          if (thermo_all || (is_def(tt[k], undef) && is_def(ss[k], undef))) {
-            rt[k] = tt[k] / pidcp_of(PT, p);
-          } else {
-            rt[k] = undef;
-            bad_th += 1;
-          }
-        }
-        if (want_rh) { // hlevelhum compute 1, :1187-1190 (ps tested with != undef only)
-          float r;
-          if ((thermo_all || (is_def(tt[k], undef) && is_def(qq[k], undef) && ss[k] != undef)) && tk_q_rh(s_ewt, tt[k], qq[k], p, r)) {
-            rr[k] = r;
-          } else {
-            rr[k] = undef;
-            bad_rh += 1;
-          }
-        }
-      }
-      if (want_rh)
-        store4_stream(P.rh + o, rr[0], rr[1], rr[2], rr[3]);
-      if (want_th)
-        store4_stream(P.theta + o, rt[0], rt[1], rt[2], rt[3]);
-    }
-  }
-  // The ewt table can reject a cell even when the inputs are ALL_DEFINED, so
-  // rh is always counted; ff / theta only need counting when tests ran.
-  if (P.n_undefined) {
-    if (CHECK && want_ff)
-      wave_count_add(P.n_undefined + lev, bad_ff);
-    if (want_rh)
-      wave_count_add(P.n_undefined + (P.count_stride ? P.count_stride : P.nlev) + lev, bad_rh);
-    if (CHECK && want_th)
-      wave_count_add(P.n_undefined + 2 * (P.count_stride ? P.count_stride : P.nlev) + lev, bad_th);
-  }
-}
-
-hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream)
-{
-  if (prm.n <= 0 || prm.nlev <= 0)
-    return hipSuccess;
-  if (prm.n % 4 != 0)
-    return hipErrorInvalidValue; // callers route ragged sizes through the per-field operators
-  const int block = 256;
-  const int n4 = prm.n >> 2;
-  int gx = (n4 + block - 1) / block;
-  if (gx > 4096)
-    gx = 4096;
-  for (int l0 = 0; l0 < prm.nlev; l0 += 65535) {
-    DerivedParams p = prm;
-    const int nl = (prm.nlev - l0 > 65535) ? 65535 : (prm.nlev - l0);
-    p.count_stride = prm.count_stride ? prm.count_stride : prm.nlev;
-    p.nlev = nl;
-    // shift the per-level pointers; counters keep the full-batch layout
-    const size_t off = (size_t)l0 * (size_t)prm.n;
-    p.u = prm.u ? prm.u + off : nullptr;
-    p.v = prm.v ? prm.v + off : nullptr;
-    p.t = prm.t ? prm.t + off : nullptr;
-    p.q = prm.q ? prm.q + off : nullptr;
-    p.ff = prm.ff ? prm.ff + off : nullptr;
-    p.rh = prm.rh ? prm.rh + off : nullptr;
-    p.theta = prm.theta ? prm.theta + off : nullptr;
-    p.alevel = prm.alevel ? prm.alevel + l0 : nullptr;
-    p.blevel = prm.blevel ? prm.blevel + l0 : nullptr;
-    p.wind_all_defined = prm.wind_all_defined ? prm.wind_all_defined + l0 : nullptr;
-    p.thermo_all_defined = prm.thermo_all_defined ? prm.thermo_all_defined + l0 : nullptr;
-    p.n_undefined = prm.n_undefined ? prm.n_undefined + l0 : nullptr;
-    if (prm.every_level_all_defined)
-      hipLaunchKernelGGL(derived_levels_kernel<false>, dim3(gx, nl), dim3(block), 0, stream, p);
-    else
-      hipLaunchKernelGGL(derived_levels_kernel<true>, dim3(gx, nl), dim3(block), 0, stream, p);
-  }
-  return hipGetLastError();
-}
-
 } // namespace mifc
 
 // ----------------------------------------------------------------------------

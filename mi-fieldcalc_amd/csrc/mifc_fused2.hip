@@ -269,9 +269,23 @@ __device__ __forceinline__ void edge_count_cells(const Fused2Params& P, const in
 // as its last read has been ISSUED: source rows r-2..r+1 are live after iteration r for TFP (its last
 // stage reads rows r-3..r-1 of the source again), r-1..r+1 for the Q-vector; intermediate rows r-3..r-1.
 template <int OP, bool CHECK>
-__global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_tile_kernel(const Fused2Params P, const int band, const int ntiles, const int n_main)
+__global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_tile_kernel(const Fused2Params P0, const int band, const int ntiles, const int n_main)
 {
   constexpr bool TFP = OP == F2_TFP;
+  // level batches: this workgroup's level (wave-uniform) selects the fields, the counters and the scalars
+  Fused2Params P = P0;
+  if (P0.n_launch_levels > 0) {
+    const int lev = P0.levels ? P0.levels[blockIdx.y] : (int)blockIdx.y;
+    const size_t off = (size_t)lev * (size_t)P0.level_stride;
+    P.a = P0.a + off;
+    P.t = P0.t ? P0.t + off : nullptr;
+    P.out = P0.out + off;
+    P.counts = P0.counts + 3 * (size_t)lev;
+    if (P0.scale_lev) {
+      P.scale = P0.scale_lev[lev];
+      P.scale2 = P0.scale2_lev[lev];
+    }
+  }
   if ((!TFP || CHECK) && (int)blockIdx.x >= n_main) { // the workgroups behind the tiles count the edge-column cells
     edge_count_cells<OP, CHECK>(P, ((int)blockIdx.x - n_main) * 64 + (int)threadIdx.x, ((int)gridDim.x - n_main) * 64);
     return;
@@ -510,9 +524,10 @@ hipError_t launch(const Fused2Params& p, hipStream_t stream)
 {
   const int interior = p.ny - 2;
   const int ntiles = (p.nx + TW - 1) / TW;
+  const int nl = p.n_launch_levels > 0 ? p.n_launch_levels : 1;
   // enough workgroups to fill the chip several times over (16-20 single-wave workgroups fit a CU),
   // bands tall enough that the 4 (source) + 2 (maps) halo rows a band re-reads stay a small fraction
-  const long want_bands = (256L * 16 * 4 + ntiles - 1) / ntiles;
+  const long want_bands = (256L * 16 * 4 + (long)ntiles * nl - 1) / ((long)ntiles * nl);
   int band = (int)((interior + want_bands - 1) / want_bands);
   if (band < 4)
     band = 4;
@@ -528,7 +543,25 @@ hipError_t launch(const Fused2Params& p, hipStream_t stream)
     if (n_edge > 256)
       n_edge = 256;
   }
-  hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(n_main + n_edge)), dim3(64), 0, stream, p, band, ntiles, n_main);
+  for (int l0 = 0; l0 < nl; l0 += 65535) { // grid.y limit
+    Fused2Params q = p;
+    const int n = nl - l0 > 65535 ? 65535 : nl - l0;
+    if (p.n_launch_levels > 0) {
+      q.n_launch_levels = n;
+      if (p.levels) {
+        q.levels = p.levels + l0;
+      } else if (l0 > 0) { // implicit numbering: shift the bases instead
+        const size_t off = (size_t)l0 * (size_t)p.level_stride;
+        q.a = p.a + off;
+        q.t = p.t ? p.t + off : nullptr;
+        q.out = p.out + off;
+        q.counts = p.counts + 3 * (size_t)l0;
+        q.scale_lev = p.scale_lev ? p.scale_lev + l0 : nullptr;
+        q.scale2_lev = p.scale2_lev ? p.scale2_lev + l0 : nullptr;
+      }
+    }
+    hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(n_main + n_edge), (unsigned)n), dim3(64), 0, stream, q, band, ntiles, n_main);
+  }
   return hipGetLastError();
 }
 

@@ -67,20 +67,22 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream);
 // recommended distance (in floats) between the levels of a device-resident batch of fields of n cells
 size_t padded_level_stride(size_t n);
 
-// Fused (ff, rh, theta) over levels, BASELINE.json config 2.
+// Fused derived variables over hybrid levels (mifc_derived.hip), BASELINE.json config 2 x nlev.
 struct DerivedParams
 {
   int n;    // cells per level
   int nlev;
-  const float *u, *v, *t, *q, *ps; // ps shared by all levels
+  const float *u, *v, *t, *h, *ps; // h: humidity input (q or RH); ps shared by all levels
   const float *alevel, *blevel;    // device float[nlev]
-  float *ff, *rh, *theta;          // any may be null
+  float *ff, *temp, *hum, *td;     // outputs, any may be null: vectorabs | hleveltemp | hlevelhum | a second hlevelhum variant
+  int temp_compute;                // hleveltemp compute after the unit remap, 1..5
+  int hum_code, td_code;           // 1 + HumKind + 4 * from_theta (0 = none)
+  float hum_tdconv, td_tdconv;     // :1181
   const unsigned char* wind_all_defined;   // device u8[nlev]
   const unsigned char* thermo_all_defined; // device u8[nlev]
-  int every_level_all_defined;             // host hint: skip all tests and counting
+  int every_level_all_defined;             // host hint: skip all tests
   float undef;
-  u64* n_undefined; // device u64[3*count_stride]: ff | rh | theta
-  int count_stride; // levels of the WHOLE batch when this launch is a chunk of it (0: nlev)
+  u64 *cnt_ff, *cnt_temp, *cnt_hum, *cnt_td; // device u64[nlev] each (level 0 of this launch first)
   // small batches (nlev <= 8, e.g. the single level of BASELINE.json config 2)
   // carry the per-level scalars in the kernel arguments: no upload before the launch
   int n_inline; // != 0: use the arrays below instead of the device arrays above
@@ -253,6 +255,9 @@ hipError_t launch_shapiro2(const ShapiroParams& prm, hipStream_t stream);
 // The four sweeps in one launch, src -> dst (two different arrays); nx % 4 == 0, 16-byte aligned.
 bool shapiro2_fused_supported(int nx, int ny, const float* src, const float* dst);
 hipError_t launch_shapiro2_fused(int nx, int ny, int all_defined, float undef, const float* src, float* dst, hipStream_t stream);
+// the same over n_launch_levels fields level_stride floats apart; entry k of the launch is level levels[k] (k if null)
+hipError_t launch_shapiro2_fused_levels(int nx, int ny, int all_defined, float undef, const float* src, float* dst, int n_launch_levels,
+                                        long level_stride, const int* levels, hipStream_t stream);
 
 // Stencil-of-a-stencil operators in one launch (mifc_fused2.hip): the
 // intermediate field(s) of thermalFrontParameter (:2266) and plevelqvector
@@ -281,6 +286,16 @@ struct Fused2Params
   // [1] cells the last pass left undefined (what the returned flag is made from)
   // [2] TFP, tested input only: cells of the last pass that only the defined-test rejected
   u64* counts;
+  // level batches (0 / null: one field): grid.y walks n_launch_levels entries; entry k is level
+  // levels[k] (or k when levels is null) -- the levels of a batch are launched in two groups, the ones
+  // whose input flag is ALL_DEFINED (no tests) and the others.  a, t, out are level_stride floats
+  // apart, the map / Coriolis fields are shared, counts holds three counters per level, and the
+  // Q-vector's scalars (they depend on the level's pressure) come from scale_lev / scale2_lev.
+  int n_launch_levels;
+  long level_stride;
+  const int* levels;
+  const float* scale_lev;
+  const float* scale2_lev;
 };
 bool fused2_supported(const Fused2Params& prm);
 hipError_t launch_fused2(const Fused2Params& prm, hipStream_t stream);

@@ -114,9 +114,14 @@ __device__ __forceinline__ float s2_update(float c, float a, float b, float s, b
 }
 
 template <bool ALL>
-__global__ __launch_bounds__(64) void shapiro2_tile_kernel(const float* __restrict__ src, float* __restrict__ dst, const int nx, const int ny,
-                                                           const float undef, const int band, const int ntiles)
+__global__ __launch_bounds__(64) void shapiro2_tile_kernel(const float* __restrict__ src0, float* __restrict__ dst0, const int nx, const int ny,
+                                                           const float undef, const int band, const int ntiles, const long level_stride,
+                                                           const int* __restrict__ levels)
 {
+  // level batches: grid.y walks the levels of this launch (entry k = level levels[k], or k)
+  const size_t level_off = (size_t)(levels ? levels[blockIdx.y] : (int)blockIdx.y) * (size_t)level_stride;
+  const float* __restrict__ src = src0 + level_off;
+  float* __restrict__ dst = dst0 + level_off;
   constexpr int RF = 5; // F rows r-3..r are live in an iteration, row r+1 lands at its end
   __shared__ float4 lds4[(RF + 3 + 1 + 3) * S2_TS / 4];
   float* ringF = reinterpret_cast<float*>(lds4);
@@ -246,18 +251,29 @@ bool shapiro2_fused_supported(int nx, int ny, const float* src, const float* dst
 
 hipError_t launch_shapiro2_fused(int nx, int ny, int all_defined, float undef, const float* src, float* dst, hipStream_t stream)
 {
+  return launch_shapiro2_fused_levels(nx, ny, all_defined, undef, src, dst, 1, 0, nullptr, stream);
+}
+
+hipError_t launch_shapiro2_fused_levels(int nx, int ny, int all_defined, float undef, const float* src, float* dst, int n_launch_levels,
+                                        long level_stride, const int* levels, hipStream_t stream)
+{
+  if (n_launch_levels <= 0)
+    return hipSuccess;
+  if (n_launch_levels > 65535)
+    return hipErrorInvalidValue;
   const int ntiles = (nx + S2_TW - 1) / S2_TW;
-  const long want_bands = (256L * 12 * 4 + ntiles - 1) / ntiles;
+  const long want_bands = (256L * 12 * 4 + (long)ntiles * n_launch_levels - 1) / ((long)ntiles * n_launch_levels);
   int band = (int)((ny + want_bands - 1) / want_bands);
   if (band < 4)
     band = 4;
   if (band > 64)
     band = 64;
   const int nbands = (ny + band - 1) / band;
+  const dim3 grid((unsigned)(nbands * ntiles), (unsigned)n_launch_levels);
   if (all_defined)
-    hipLaunchKernelGGL((shapiro2_tile_kernel<true>), dim3((unsigned)(nbands * ntiles)), dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles);
+    hipLaunchKernelGGL((shapiro2_tile_kernel<true>), grid, dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles, level_stride, levels);
   else
-    hipLaunchKernelGGL((shapiro2_tile_kernel<false>), dim3((unsigned)(nbands * ntiles)), dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles);
+    hipLaunchKernelGGL((shapiro2_tile_kernel<false>), grid, dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles, level_stride, levels);
   return hipGetLastError();
 }
 

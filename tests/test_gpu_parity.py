@@ -759,3 +759,75 @@ def test_one_launch_kernels_equal_their_multi_pass_paths_on_a_large_field(gpu_ct
     for k in one:
         assert one[k][1] == many[k][1], (k, one[k][1], many[k][1])
         assert cases.same_bits(one[k][0], many[k][0], nan_payload=False), k
+
+
+# ------------------------------------------------------------------ the f1 operators over level batches (shared map factors)
+@pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 5), (129, 21, 3), (1440, 37, 6), (240, 9, 4)])
+@pytest.mark.parametrize("device", [False, True])
+def test_stencil_levels_ex_f1_operators(gpu_ctx, oracle, nx, ny, nlev, device):
+    """mifc_stencil_levels_ex: advection, thermalFrontParameter, plevelqvector (pressure per level) and
+    shapiro2_filter over a batch == the per-level reference call, flags included.  Mixed input flags in
+    one batch (the two-stage kernels run the ALL_DEFINED levels and the tested ones as separate launches),
+    a level whose flag lies, and a width the one-launch kernels do not take (129: level-by-level path)."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    xm, ym, fcor = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 808 + nx, nlev=nlev)
+    z = np.stack([synth.scalar_field(nx, ny, 900 + l) for l in range(nlev)])
+    flags = np.full(nlev, SOME, np.int32)
+    flags[0] = ALL
+    for l in range(1, nlev):
+        if l % 2:
+            z[l] = synth.sprinkle_undef(z[l], 20 + l, 0.03)
+            u[l] = synth.sprinkle_undef(u[l], 30 + l, 0.03)
+    if nlev > 2:
+        flags[nlev - 1] = ALL  # clean or not, the caller promises ALL_DEFINED: no tests
+        z[2, ny // 3:, : max(3, nx // 2)] = np.float32(5432.0)  # a plateau: |grad| == 0 is rejected whatever the flag says
+    with np.errstate(all="ignore"):
+        bad = (z == cases.UNDEF) | np.isnan(z)
+        t = np.where(bad, z, np.float32(250.0) + np.float32(0.05) * (z - np.float32(5500.0))).astype(np.float32)
+    pres = np.array([1000.0, 850.0, 700.0, 500.0, 300.0, 250.0][:nlev], np.float32)
+    dev = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()) if device else (lambda a: a)
+    host = (lambda a: a.cpu().numpy()) if device else (lambda a: a)
+    dxm, dym, dfc = dev(xm), dev(ym), dev(fcor)
+
+    def check(name, res, per_level):
+        assert res is not None, name
+        out, fo = res
+        out = host(out)
+        for l in range(nlev):
+            ok, e, f = per_level(l)
+            assert ok and cases.same_bits(out[l], e, nan_payload=False), (name, l)
+            assert fo[l] == f, (name, l, fo[l], f)
+
+    check("advection", gpu_ctx.stencil_levels_ex("advection", dev(z), dev(u), dev(v), dxm, dym, scalar=1.0 / 3600.0, fdefined=flags),
+          lambda l: oracle.call("advection", nx, ny, z[l], u[l], v[l], xm, ym, 1.0 / 3600.0, fdefined=int(flags[l])))
+    check("tfp", gpu_ctx.stencil_levels_ex("thermalFrontParameter", dev(z), xmapr=dxm, ymapr=dym, fdefined=flags),
+          lambda l: oracle.call("thermalFrontParameter", nx, ny, z[l], xm, ym, fdefined=int(flags[l])))
+    for c in (1, 2, 3, 4):
+        check("qvector%d" % c, gpu_ctx.stencil_levels_ex("plevelqvector", dev(z), dev(t), None, dxm, dym, dfc, level_scalars=pres, compute=c, fdefined=flags),
+              lambda l: oracle.call("plevelqvector", nx, ny, z[l], t[l], xm, ym, fcor, float(pres[l]), c, fdefined=int(flags[l])))
+    check("shapiro", gpu_ctx.stencil_levels_ex("shapiro2_filter", dev(z), fdefined=flags),
+          lambda l: oracle.call("shapiro2_filter", nx, ny, z[l], fdefined=int(flags[l])))
+    # invalid arguments -> false, like the per-level calls
+    assert gpu_ctx.stencil_levels_ex("plevelqvector", dev(z), dev(t), None, dxm, dym, dfc, level_scalars=-pres, compute=1, fdefined=flags) is None
+    assert gpu_ctx.stencil_levels_ex("plevelqvector", dev(z), dev(t), None, dxm, dym, dfc, level_scalars=pres, compute=7, fdefined=flags) is None
+
+
+def test_shapiro_levels_in_place(gpu_ctx, oracle):
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 484, 30, 3
+    z = np.stack([synth.scalar_field(nx, ny, 70 + l) for l in range(nlev)])
+    z[1] = synth.sprinkle_undef(z[1], 3, 0.02)
+    flags = np.array([ALL, SOME, SOME], np.int32)
+    dz = torch.from_numpy(z.copy()).cuda()
+    out, fo = gpu_ctx.stencil_levels_ex("shapiro2_filter", dz, fdefined=flags, out0=dz)
+    assert out.data_ptr() == dz.data_ptr() and np.all(fo == ALL)
+    for l in range(nlev):
+        ok, e, _ = oracle.call("shapiro2_filter", nx, ny, z[l], fdefined=int(flags[l]))
+        assert cases.same_bits(dz[l].cpu().numpy(), e, nan_payload=False), l

@@ -236,6 +236,118 @@ def test_config2_derived_batch_1440x720(gpu_ctx, oracle, nlev, mode):
             assert (flags["ff"][l], flags["rh"][l], flags["theta"][l]) == (f_ff, f_rh, f_th)
 
 
+def _check_derived_batch(gpu_ctx, oracle, u, v, t, h, ps, a, b, fw, ft, temp, hum, hum2, ff, device):
+    """One mifc_hlevel_derived_batch call against the per-level reference calls it stands for."""
+    import torch
+
+    nlev, ny, nx = t.shape
+    args = [u, v, t, h, ps]
+    if device:
+        args = [torch.from_numpy(np.ascontiguousarray(x)).cuda() for x in args]
+    tag = "temp=%s hum=%s hum2=%s" % (temp, hum, hum2)
+    call = lambda: gpu_ctx.hlevel_derived_batch(*args, a, b, temp=temp, hum=hum, hum2=hum2, ff=ff, fdef_wind=fw, fdef_thermo=ft)
+    if temp is not None:
+        c = temp[1]
+        if c < 3:
+            c = 1 if temp[0] == "celsius" else (2 if temp[0] == "kelvin" else c)
+        if not 1 <= c <= 5:  # the reference would leave cells unwritten (:1080-1090): the batched entry refuses, with a message
+            with pytest.raises(RuntimeError):
+                call()
+            return
+    if any(w is not None and not 1 <= w[1] <= 12 for w in (hum, hum2)):  # hlevelhum returns false (:1168)
+        assert call() is None, tag
+        return
+    res = call()
+    assert res is not None, tag
+    out, flags = res
+    get = (lambda x: x.cpu().numpy()) if device else (lambda x: x)
+    for l in range(nlev):
+        if ff:
+            ok, e, f = oracle.call("vectorabs", nx, ny, u[l], v[l], fdefined=int(fw[l]))
+            gpu_util.compare(dict(label="ff " + tag, undef=cases.UNDEF, op="vectorabs"), get(out["ff"])[l], e, True)
+            assert flags["ff"][l] == f, tag
+        if temp is not None:
+            cargs = [t[l], ps, float(a[l]), float(b[l]), temp[0], temp[1]]
+            ok, e, f = oracle.call("hleveltemp", nx, ny, *cargs, fdefined=int(ft[l]))
+            assert ok
+            case = dict(label="temp l%d %s" % (l, tag), undef=cases.UNDEF, op="hleveltemp", args=cargs)
+            gpu_util.compare(case, get(out["temp"])[l], e, False)
+            assert flags["temp"][l] == f, tag
+        for name, w in (("hum", hum), ("hum2", hum2)):
+            if w is None:
+                continue
+            cargs = [t[l], h[l], ps, float(a[l]), float(b[l]), w[0], w[1]]
+            ok, e, f = oracle.call("hlevelhum", nx, ny, *cargs, fdefined=int(ft[l]))
+            assert ok
+            case = dict(label="%s l%d %s" % (name, l, tag), undef=cases.UNDEF, op="hlevelhum", args=cargs)
+            gpu_util.compare(case, get(out[name])[l], e, not gpu_util.uses_device_powf(case))
+            assert flags[name][l] == f, (tag, name, l)
+
+
+@pytest.mark.parametrize("nlev", [3, 9])
+def test_derived_batch_every_variant(gpu_ctx, oracle, nlev):
+    """Every hleveltemp / hlevelhum variant the batched entry offers (compile-time combinations and the
+    generic instantiation; per-level scalars in the kernel arguments for nlev <= 8, device tables above),
+    each against the per-level reference call, flags included; invalid computes return None."""
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny = 64, 36
+    u, v = synth.wind(nx, ny, 311, nlev=nlev)
+    t, q, ps = synth.thermo(nx, ny, 312, nlev=nlev)
+    a, b = synth.hybrid_levels(max(nlev, 3))
+    a, b = a[:nlev], b[:nlev]
+    rh = synth.uniform((nlev, ny, nx), 313, 0.5, 110.0).astype(np.float32)
+    fw = np.full(nlev, SOME, np.int32)
+    ft = fw.copy()
+    fw[0] = ft[0] = ALL  # level 0: the no-test path (its fields stay clean)
+    for l in range(1, nlev):
+        u[l] = synth.sprinkle_undef(u[l], 50 + l, 0.03)
+        t[l] = synth.sprinkle_undef(t[l], 60 + l, 0.03)
+        q[l] = synth.sprinkle_undef(q[l], 70 + l, 0.03)
+        rh[l] = synth.sprinkle_undef(rh[l], 75 + l, 0.03)
+    ps = synth.sprinkle_undef(ps, 80, 0.02, nan_every=3)
+    ps[0, :4] = 1000.0
+    t[0, 0, :8] = 400.0  # outside the saturation table
+    k = 0
+    for c in range(0, 7):
+        for unit in ("celsius", "kelvin", ""):
+            _check_derived_batch(gpu_ctx, oracle, u, v, t, q, ps, a, b, fw, ft, (unit, c), None, None, ff=bool(k % 2), device=bool(k % 3 == 0))
+            k += 1
+    for c in range(0, 14):
+        for unit in ("celsius", "kelvin"):
+            h = q if c in (1, 2, 5, 6, 9, 10) else rh
+            _check_derived_batch(gpu_ctx, oracle, u, v, t, h, ps, a, b, fw, ft, None, (unit, c), None, ff=False, device=bool(k % 2))
+            k += 1
+    # the compile-time combinations and mixed ones
+    for temp, hum, hum2, ff in ((("", 3), ("", 1), None, True), (("", 3), ("", 1), ("", 9), True), (("", 3), ("", 1), None, False),
+                                (("", 3), ("", 1), ("", 9), False), (None, None, None, True), (("kelvin", 1), ("", 9), ("celsius", 9), True),
+                                (("", 4), ("", 5), ("", 1), False), (("", 5), ("", 2), ("", 10), True), (None, ("", 1), ("", 7), True)):
+        hh = q
+        _check_derived_batch(gpu_ctx, oracle, u, v, t, hh, ps, a, b, fw, ft, temp, hum, hum2, ff, device=True)
+    # a bad hybrid level -> false, like the reference (:298)
+    assert gpu_ctx.hlevel_derived_batch(u, v, t, q, ps, -a, b, temp=("", 3), fdef_wind=fw, fdef_thermo=ft) is None
+
+
+@pytest.mark.parametrize("mode", ["all", "some"])
+def test_config2_quartet_with_dew_point_1440x720(gpu_ctx, oracle, mode):
+    """ff + theta + RH + dew point (K) in one launch at BASELINE.json config 2's size, 9 levels."""
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 1440, 720, 9
+    u, v = synth.wind(nx, ny, 411, nlev=nlev)
+    t, q, ps = synth.thermo(nx, ny, 412, nlev=nlev)
+    a, b = synth.hybrid_levels(nlev)
+    fw = np.full(nlev, ALL if mode == "all" else SOME, np.int32)
+    ft = fw.copy()
+    if mode == "some":
+        for l in range(nlev):
+            u[l] = synth.sprinkle_undef(u[l], 50 + l, 0.01)
+            t[l] = synth.sprinkle_undef(t[l], 60 + l, 0.01)
+            q[l] = synth.sprinkle_undef(q[l], 70 + l, 0.01)
+        ps = synth.sprinkle_undef(ps, 80, 0.01, nan_every=0)
+    _check_derived_batch(gpu_ctx, oracle, u, v, t, q, ps, a, b, fw, ft, ("", 3), ("", 1), ("", 9), True, device=True)
+
+
 # ------------------------------------------------------------------ config 5: one member through the pipeline
 def test_config5_one_member_pipeline(gpu_ctx, oracle):
     """One ensemble member of BASELINE.json config 5 (1440 x 720 x 137, device resident) through the
