@@ -236,6 +236,15 @@ int mifc_fieldOPERconstant(mifc_ctx* ctx, int compute, int nx, int ny, const flo
 int mifc_constantOPERfield(mifc_ctx* ctx, int compute, int nx, int ny, float value, const float* field, float* fres, int* fdefined, float undef,
                            int memkind);
 
+/* ---- EXTENSION, NOT part of miutil::fieldcalc ------------------------------------------------
+ * BASELINE.json's north_star names "wind speed/direction from u/v"; the reference has the speed
+ * (vectorabs) but no direction function (FieldCalculations.cc:1951-1952 mention it in a comment
+ * only), so there is no reference result to be identical to.  Defined here as the meteorological
+ * direction the wind blows FROM, degrees clockwise from north, in [0, 360):
+ *   dd = 270 - atan2(v, u) * 180 / pi   (calm: 0),   undefined where u or v is undefined,
+ * with the flag handling of vectorabs (.cc:1819-1841).  Parity is against this definition only. */
+int mifc_winddir(mifc_ctx* ctx, int nx, int ny, const float* u, const float* v, float* dd, int* fdefined, float undef, int memkind);
+
 /* ---- reductions over ensemble members ---------------------
  * sumFields .h:284 / .cc:2671; meanValue .h:286 / .cc:2696; stddevValue .h:289 / .cc:2726;
  * extremeValue .h:292 / .cc:2759; probability .h:294 / .cc:2807.

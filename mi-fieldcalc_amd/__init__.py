@@ -393,6 +393,11 @@ class Context:
     def vesselIcingMertins(self, airtemp, seatemp, u, v, sal, aice, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
         return self._single("mifc_vesselIcingMertins", [airtemp, seatemp, u, v, sal, aice], [], [out], fdefined, undef)
 
+    def winddir(self, u, v, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
+        """EXTENSION (no reference function): meteorological wind direction, degrees the wind blows FROM,
+        dd = 270 - atan2(v, u) * 180 / pi in [0, 360), calm -> 0; see include/mifc.h."""
+        return self._single("mifc_winddir", [u, v], [], [out], fdefined, undef)
+
     def minvalueFields(self, field1, field2, fdefined=SOME_DEFINED, undef=UNDEF, out=None):
         return self._single("mifc_minvalueFields", [field1, field2], [], [out], fdefined, undef)
 

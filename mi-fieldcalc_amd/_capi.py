@@ -97,6 +97,7 @@ SIGNATURES = {
     "mifc_shapiro2_filter": ("i", ["ctx", "i", "i", "p", "p", "pi", "f", "i"]),
     "mifc_vesselIcingOverland": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_vesselIcingMertins": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_winddir": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
     "mifc_minvalueFields": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
     "mifc_maxvalueFields": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
     "mifc_minvalueFieldConst": ("i", ["ctx", "i", "i", "p", "f", "p", "pi", "f", "i"]),

@@ -637,6 +637,16 @@ static int vessel_icing(mifc_ctx* c, int model, int nx, int ny, const float* air
     pc.in[k] = in[k];
   return run_pointwise(c, nx, ny, pc, icing, fdefined, memkind);
 }
+// EXTENSION: not a miutil::fieldcalc function (see include/mifc.h)
+int mifc_winddir(mifc_ctx* c, int nx, int ny, const float* u, const float* v, float* dd, int* fdefined, float undef, int memkind)
+{
+  CTX_OR_FAIL(c);
+  PwCall pc = pw_call(mifc::PW_WINDDIR, 0, 2, fdefined, undef);
+  pc.in[0] = u;
+  pc.in[1] = v;
+  return run_pointwise(c, nx, ny, pc, dd, fdefined, memkind);
+}
+
 int mifc_vesselIcingOverland(mifc_ctx* c, int nx, int ny, const float* airtemp, const float* seatemp, const float* u, const float* v,
                              const float* sal, const float* aice, float* icing, int* fdefined, float undef, int memkind)
 {

@@ -200,10 +200,11 @@ __device__ __attribute__((noinline)) float pow_kappa_slow(float x)
   return (float)exp2((double)MIFC_K_KAPPA * log2((double)x));
 }
 
-__device__ __forceinline__ float pow_kappa(const PowTables& T, float x)
+// log2 of a positive NORMAL float, in double.  Absolute error ~5e-12 (table of 16 centres, |r| <= 1/32,
+// series to r^6), i.e. fine as the inner function of a power; functions that return the logarithm itself
+// use log2_near_one() around 1, where the RELATIVE error matters.
+__device__ __forceinline__ double log2_tab(const PowTables& T, float x)
 {
-  if (!(x >= 1.0e-30f && x <= 1.0e30f))
-    return pow_kappa_slow(x);
   const int ix = __float_as_int(x);
   const int e = (ix - 0x3f3504f3) >> 23; // x / 2^e in [sqrt(1/2), sqrt(2))
   const int im = ix - (e << 23);
@@ -216,8 +217,24 @@ __device__ __forceinline__ float pow_kappa(const PowTables& T, float x)
   p = fma(p, r, 1.0 / 3.0);
   p = fma(p, r, -0.5);
   p = fma(p, r, 1.0);
-  const double log2x = fma(r * 1.4426950408889634 /* 1/ln 2 */, p, T.logt[2 * i + 1] + (double)e);
-  const double t = (double)MIFC_K_KAPPA * log2x;
+  return fma(r * 1.4426950408889634 /* 1/ln 2 */, p, T.logt[2 * i + 1] + (double)e);
+}
+// log2(x) for |x - 1| < 1/32: r = x - 1 is exact, the series then has a relative error below 2e-10
+__device__ __forceinline__ double log2_near_one(float x)
+{
+  const double r = (double)x - 1.0;
+  double p = 1.0 / 7.0;
+  p = fma(p, r, -1.0 / 6.0);
+  p = fma(p, r, 1.0 / 5.0);
+  p = fma(p, r, -1.0 / 4.0);
+  p = fma(p, r, 1.0 / 3.0);
+  p = fma(p, r, -0.5);
+  p = fma(p, r, 1.0);
+  return r * 1.4426950408889634 * p;
+}
+// 2^t in double for |t| < 1024 (relative error ~2e-12): k = rint(32 t), 2^(k>>5) * 2^((k&31)/32) * e^g
+__device__ __forceinline__ double exp2_tab(const PowTables& T, double t)
+{
   const double k = rint(t * 32.0);
   const double g = fma(k, -1.0 / 32.0, t) * 0.6931471805599453 /* ln 2 */;
   const int ki = (int)k;
@@ -226,7 +243,65 @@ __device__ __forceinline__ float pow_kappa(const PowTables& T, float x)
   q = fma(q, g, 0.5);
   q = fma(q, g, 1.0);
   q = fma(q, g, 1.0);
-  return (float)ldexp(T.expt[ki & 31] * q, ki >> 5);
+  return ldexp(T.expt[ki & 31] * q, ki >> 5);
+}
+
+__device__ __forceinline__ float pow_kappa(const PowTables& T, float x)
+{
+  if (!(x >= 1.0e-30f && x <= 1.0e30f))
+    return pow_kappa_slow(x);
+  return (float)exp2_tab(T, (double)MIFC_K_KAPPA * log2_tab(T, x));
+}
+
+// ---- the float libm functions of the catalogue (logf, log10f, expf, powf and the double exp / pow the
+// reference rounds to float), evaluated in double with the tables above and rounded once: within 1 ulp of
+// the correctly rounded float (glibc's own float functions are), far inside the 1e-5 bar.  Arguments
+// outside the fast domain (zero, negative, subnormal, infinite, NaN, huge exponents) take the device
+// library's double function, out of line.
+__device__ __attribute__((noinline)) float libm_log_slow(float x, int base10)
+{
+  return (float)(base10 ? log10((double)x) : log((double)x));
+}
+__device__ __attribute__((noinline)) float libm_exp_slow(double t, int base10)
+{
+  return (float)(base10 ? pow(10.0, t) : exp(t));
+}
+__device__ __attribute__((noinline)) float libm_pow_slow(double a, double b)
+{
+  return (float)pow(a, b);
+}
+__device__ __forceinline__ bool positive_normal(float x)
+{
+  return x >= 1.17549435e-38f && x <= 3.40282347e38f;
+}
+__device__ __forceinline__ double log2_any(const PowTables& T, float x) // x positive normal
+{
+  return (__builtin_fabsf(x - 1.0f) < 0.03125f) ? log2_near_one(x) : log2_tab(T, x);
+}
+// logf / log10f
+__device__ __forceinline__ float log_float(const PowTables& T, float x, bool base10)
+{
+  if (!positive_normal(x))
+    return libm_log_slow(x, base10 ? 1 : 0);
+  return (float)(log2_any(T, x) * (base10 ? 0.30102999566398120 /* log10 2 */ : 0.6931471805599453 /* ln 2 */));
+}
+// (float)exp(a) / (float)pow(10, a) for a double argument
+__device__ __forceinline__ float exp_float(const PowTables& T, double a, bool base10)
+{
+  const double t = a * (base10 ? 3.3219280948873623 /* log2 10 */ : 1.4426950408889634 /* log2 e */);
+  if (!(t > -1000.0 && t < 1000.0))
+    return libm_exp_slow(a, base10 ? 1 : 0);
+  return (float)exp2_tab(T, t);
+}
+// (float)pow((double)a, b)
+__device__ __forceinline__ float pow_float(const PowTables& T, float a, double b)
+{
+  if (!positive_normal(a))
+    return libm_pow_slow((double)a, b);
+  const double t = b * log2_any(T, a);
+  if (!(t > -1000.0 && t < 1000.0))
+    return libm_pow_slow((double)a, b);
+  return (float)exp2_tab(T, t);
 }
 
 __device__ __forceinline__ float pidcp_of(const PowTables& T, float p)
@@ -332,6 +407,23 @@ __device__ __forceinline__ float absval(float x, float y)
   return sqrtf(x * x + y * y);
 }
 
+// (float)(0.5 * (double)m * (double)d) for floats m and d -- the "float-rounded partial" of the reference's
+// gradient-type operators (e.g. FieldCalculations.cc:2015, :2040, :2445).  Both factors are float-born, so
+// the double product 0.5*m*d is EXACT (25 + 24 significant bits) and the expression is the correctly rounded
+// float of the exact product.  A float multiply of two floats whose exact product is the same number gives
+// that very rounding; what has to be exact is the halving of one factor, and halving the factor of larger
+// magnitude always is (it is either >= 2^-125, where halving only lowers the exponent, or both factors are
+// so small that the product rounds to the same signed zero either way).  Five fp64-pipe instructions
+// (three conversions, two multiplies) become two selects and two float multiplies; the result is the
+// reference's bit for bit, infinities, zeros and NaNs included (a NaN's payload may differ).
+__device__ __forceinline__ float half_prod(float m, float d)
+{
+  const bool m_larger = __builtin_fabsf(m) >= __builtin_fabsf(d);
+  const float a = m_larger ? 0.5f * m : m;
+  const float b = m_larger ? d : 0.5f * d;
+  return a * b;
+}
+
 // ---- stencil point formulas (double-promoted; inputs are float differences)
 #ifdef MIFC_EXPERIMENT_F32_COMBINE
 // NOT parity-correct: float-only combine, exists solely so that tools/ can
@@ -363,6 +455,23 @@ __device__ __forceinline__ float f_diverg(float xm, float ym, float dudx, float 
   return (float)__builtin_fma(0.5 * (double)xm, (double)dudx, 0.5 * (double)ym * (double)dvdy);
 }
 #endif
+
+// ---- EXTENSION (no reference function; BASELINE.json's north_star names "wind direction from u/v",
+// FieldCalculations.cc:1951-1952 only mentions it in a comment): the meteorological wind direction,
+// i.e. where the wind blows FROM, in degrees clockwise from north:
+//   dd = 270 - atan2(v, u) * 180 / pi, brought into [0, 360); calm (u == v == 0) gives 0.
+// Evaluated in float (atan2f); the definition, not a reference result, is what tests pin.
+__device__ __forceinline__ float wind_direction(float u, float v)
+{
+  if (u == 0.f && v == 0.f)
+    return 0.f;
+  float dd = 270.f - atan2f(v, u) * 57.29577951308232f;
+  if (dd >= 360.f)
+    dd -= 360.f;
+  if (dd < 0.f)
+    dd += 360.f;
+  return dd;
+}
 
 // ---- undefined-cell counting: one atomic per wave, none when nothing to add
 __device__ __forceinline__ void wave_count_add(u64* counter, unsigned int my_count)

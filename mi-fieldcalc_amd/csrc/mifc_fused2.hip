@@ -130,8 +130,8 @@ __device__ __forceinline__ float tfp_absdelt(float s, float w, float e, float n,
     ok = !(either_nan(s, w) || either_nan(e, n));
   else
     ok = !CHECK || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef));
-  const float dfdx = (float)(0.5 * (double)xm * (double)(e - w));
-  const float dfdy = (float)(0.5 * (double)ym * (double)(n - s));
+  const float dfdx = half_prod(xm, e - w);
+  const float dfdy = half_prod(ym, n - s);
   const float g = absval(dfdx, dfdy);
   if (CANON) // a computed NaN, or a computed value that happens to equal undef, is undefined to the next pass (:2290)
     return (ok && is_def(g, undef)) ? g : __builtin_nanf("");
@@ -163,8 +163,8 @@ __device__ __forceinline__ float tfp_point(float ts, float tw, float te, float t
   ok = def && g != 0;
   rejected_by_test_only = CHECK && !def && g != 0;
   const double hx = 0.5 * (double)xm, hy = 0.5 * (double)ym;
-  const float dabsdeltdx = (float)(hx * (double)(ge - gw));
-  const float dabsdeltdy = (float)(hy * (double)(gn - gs));
+  const float dabsdeltdx = half_prod(xm, ge - gw);
+  const float dabsdeltdy = half_prod(ym, gn - gs);
   const double gd = (double)g, ginv = shared_reciprocal(gd);
   const float dtdxa = (float)quotient(hx * (double)(te - tw), gd, ginv);
   const float dtdya = (float)quotient(hy * (double)(tn - ts), gd, ginv);
@@ -178,16 +178,17 @@ __device__ __forceinline__ float qvec_point(float us, float uw, float ue, float 
   ok = us != undef && uw != undef && ue != undef && un != undef && vs != undef && vw != undef && ve != undef && vn != undef && ts != undef &&
        tw != undef && te != undef && tn != undef;
   const double hx = 0.5 * (double)xm, hy = 0.5 * (double)ym;
-  const float dtdx = (float)(hx * (double)scale * (double)(te - tw));
-  const float dtdy = (float)(hy * (double)scale * (double)(tn - ts));
+  // scale == 1 (compute 1, 3: temperature as it is): the product has two float-born factors again
+  const float dtdx = scale == 1.0f ? half_prod(xm, te - tw) : (float)(hx * (double)scale * (double)(te - tw));
+  const float dtdy = scale == 1.0f ? half_prod(ym, tn - ts) : (float)(hy * (double)scale * (double)(tn - ts));
   float q;
   if (OP == F2_QVEC_X) {
-    const float dugdx = (float)(hx * (double)(ue - uw));
-    const float dvgdx = (float)(hx * (double)(ve - vw));
+    const float dugdx = half_prod(xm, ue - uw);
+    const float dvgdx = half_prod(xm, ve - vw);
     q = scale2 * (dugdx * dtdx + dvgdx * dtdy);
   } else {
-    const float dugdy = (float)(hy * (double)(un - us));
-    const float dvgdy = (float)(hy * (double)(vn - vs));
+    const float dugdy = half_prod(ym, un - us);
+    const float dvgdy = half_prod(ym, vn - vs);
     q = scale2 * (dugdy * dtdx + dvgdy * dtdy);
   }
   return ok ? q : undef;

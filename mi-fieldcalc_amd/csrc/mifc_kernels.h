@@ -123,7 +123,10 @@ enum PwOp {
   PW_CONST_OP_FIELD,  // constantOPERfield :2647
   // FieldCalculationsVesselIcing.cc: vesselIcingOverland :77 (compute 1), vesselIcingMertins :114 (2);
   // in = airtemp, seatemp, u, v, sal, aice
-  PW_VESSEL_ICING
+  PW_VESSEL_ICING,
+  // EXTENSION, no reference function (BASELINE.json names "wind direction from u/v"):
+  // meteorological direction the wind blows FROM, degrees clockwise from north; in = u, v
+  PW_WINDDIR
 };
 
 struct PwParams

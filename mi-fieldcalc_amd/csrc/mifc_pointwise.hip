@@ -46,21 +46,22 @@ PW_TRAITS(PW_BOYDEN, 3, false, false);
 PW_TRAITS(PW_SWEAT, 8, false, false);
 PW_TRAITS(PW_SOUNDSPEED, 2, false, false);
 PW_TRAITS(PW_ADDCONST, 1, false, false);
-PW_TRAITS(PW_ABSHUM, 2, false, false);
-PW_TRAITS(PW_WINDCOOLING, 3, false, false);
+PW_TRAITS(PW_ABSHUM, 2, false, true);
+PW_TRAITS(PW_WINDCOOLING, 3, false, true);
 PW_TRAITS(PW_UNDERCOOLED, 3, false, false);
 PW_TRAITS(PW_FLIGHTLEVEL, 1, false, false);
-PW_TRAITS(PW_SNOWCM, 3, false, false);
+PW_TRAITS(PW_SNOWCM, 3, false, true);
 PW_TRAITS(PW_CLASSES, 1, false, false);
 PW_TRAITS(PW_MINMAX_FIELDS, 2, false, false);
 PW_TRAITS(PW_MINMAX_CONST, 1, false, false);
-PW_TRAITS(PW_MATH, 1, false, false);
+PW_TRAITS(PW_MATH, 1, false, true);
 PW_TRAITS(PW_REPLACE, 1, false, false);
 PW_TRAITS(PW_FILL, 0, false, false);
 PW_TRAITS(PW_FIELD_OP_FIELD, 2, false, false);
 PW_TRAITS(PW_FIELD_OP_CONST, 1, false, false);
 PW_TRAITS(PW_CONST_OP_FIELD, 1, false, false);
 PW_TRAITS(PW_VESSEL_ICING, 6, false, false);
+PW_TRAITS(PW_WINDDIR, 2, false, false);
 #undef PW_TRAITS
 
 // MetConstants.h:46 (rcp, cplr, exl), :53 (ms2knots), :88-90 (flight-level tables)
@@ -226,7 +227,9 @@ __device__ __forceinline__ int pw_point(const PwParams& P, const float* tab, con
     const float Tc = 647.096f, Pc = 220640.f;
     const float v = 1 - x[0] / Tc, tii = 1 / x[0];
     const float v2 = v * v, v3 = v * v2, v4 = v2 * v2, v1_5 = (float)((double)v * sqrt((double)v)), v3_5 = v2 * v1_5, v7_5 = v4 * v3_5;
-    const float Pws = (float)((double)Pc * exp((double)(Tc * tii * (C1 * v + C2 * v1_5 + C3 * v3 + C4 * v3_5 + C5 * v4 + C6 * v7_5))));
+    const double ex = (double)(Tc * tii * (C1 * v + C2 * v1_5 + C3 * v3 + C4 * v3_5 + C5 * v4 + C6 * v7_5));
+    const double t2 = ex * 1.4426950408889634; // exp(ex) = 2^(ex * log2 e), see exp_float()
+    const float Pws = (float)((double)Pc * ((t2 > -1000.0 && t2 < 1000.0) ? exp2_tab(PT, t2) : exp(ex)));
     const float Pw = Pws * x[1];
     r = C * Pw * 100 * tii;
     return PW_OK;
@@ -235,7 +238,7 @@ __device__ __forceinline__ int pw_point(const PwParams& P, const float* tab, con
     const float tc = x[0] - s[0];
     const float ff = (float)((double)absval(x[1], x[2]) * 3.6);
     // powf(ff, 0.16f): taken in double and rounded once (glibc's powf is correctly rounded in all but rare cases)
-    const float ffpow = (float)pow((double)ff, (double)0.16f);
+    const float ffpow = pow_float(PT, ff, (double)0.16f);
     float d = (float)(13.12 + 0.6215 * (double)tc - 11.37 * (double)ffpow + 0.3965 * (double)tc * (double)ffpow);
     if (d > 0.f)
       d = 0.f;
@@ -275,7 +278,8 @@ __device__ __forceinline__ int pw_point(const PwParams& P, const float* tab, con
       return PW_OK;
     }
     const float t = (float)((double)(x[1] + x[2]) / 2.);
-    const double ex = exp(((double)t - 274.3) * 3.5);
+    const double ea = ((double)t - 274.3) * 3.5, et2 = ea * 1.4426950408889634;
+    const double ex = (et2 > -1000.0 && et2 < 1000.0) ? exp2_tab(PT, et2) : exp(ea);
     const float logit_t = (float)((1 - ex) / (1 + ex));
     const double q = ((double)t - 252.0) / 20.0;
     const float mm2cm_t = (float)(0.13 / (0.02 + 0.1 * q * q));
@@ -309,19 +313,19 @@ __device__ __forceinline__ int pw_point(const PwParams& P, const float* tab, con
       r = fabsf(x[0]);
       break;
     case 2:
-      r = (float)log10(a);
+      r = log_float(PT, x[0], true);
       break;
     case 3:
-      r = (float)pow(10.0, a); // math_util.h:121-125 is double already
+      r = exp_float(PT, a, true); // math_util.h:121-125 is double already
       break;
     case 4:
-      r = (float)log(a);
+      r = log_float(PT, x[0], false);
       break;
     case 5:
-      r = (float)exp(a);
+      r = exp_float(PT, a, false);
       break;
     default:
-      r = (float)pow(a, (double)s[0]);
+      r = pow_float(PT, x[0], (double)s[0]);
       break;
     }
     return PW_OK;
@@ -373,6 +377,10 @@ __device__ __forceinline__ int pw_point(const PwParams& P, const float* tab, con
       r = x[0] / s[0];
       break;
     }
+    return PW_OK;
+  }
+  if (OP == PW_WINDDIR) { // extension: see wind_direction() in mifc_device.h
+    r = wind_direction(x[0], x[1]);
     return PW_OK;
   }
   if (OP == PW_VESSEL_ICING) { // FieldCalculationsVesselIcing.cc:93-104 (Overland), :125-171 (Mertins); x = airtemp, seatemp, u, v, sal, aice
@@ -644,6 +652,7 @@ hipError_t launch_pointwise(const PwParams& prm, hipStream_t stream)
     PW_CASE(PW_FIELD_OP_CONST);
     PW_CASE(PW_CONST_OP_FIELD);
     PW_CASE(PW_VESSEL_ICING);
+    PW_CASE(PW_WINDDIR);
 #undef PW_CASE
   default:
     return hipErrorInvalidValue;

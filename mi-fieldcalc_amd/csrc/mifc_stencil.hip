@@ -77,11 +77,11 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
     if (CHECK && !(all || (is_def(as, undef) && is_def(aw, undef) && is_def(ae, undef) && is_def(an, undef) && is_def(bs, undef) && is_def(bw, undef) &&
                            is_def(be, undef) && is_def(bn, undef))))
       return false;
-    const double hx = 0.5 * (double)P.xmapr[p], hy = 0.5 * (double)P.ymapr[p];
-    const float df1dx = (float)(hx * (double)(ae - aw));
-    const float df1dy = (float)(hy * (double)(an - as));
-    const float df2dx = (float)(hx * (double)(be - bw));
-    const float df2dy = (float)(hy * (double)(bn - bs));
+    const float xm = P.xmapr[p], ym = P.ymapr[p];
+    const float df1dx = half_prod(xm, ae - aw);
+    const float df1dy = half_prod(ym, an - as);
+    const float df2dx = half_prod(xm, be - bw);
+    const float df2dy = half_prod(ym, bn - bs);
     o.o0 = df1dx * df2dy - df1dy * df2dx;
     return true;
   }
@@ -95,8 +95,8 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
     if (!(def && gc != 0))
       return false;
     const double hx = 0.5 * (double)P.xmapr[p], hy = 0.5 * (double)P.ymapr[p];
-    const float dabsdeltdx = (float)(hx * (double)(ge - gw));
-    const float dabsdeltdy = (float)(hy * (double)(gn - gs));
+    const float dabsdeltdx = half_prod(P.xmapr[p], ge - gw);
+    const float dabsdeltdy = half_prod(P.ymapr[p], gn - gs);
     const float dtdxa = (float)(hx * (double)(te - tw) / (double)gc);
     const float dtdya = (float)(hy * (double)(tn - ts) / (double)gc);
     o.o0 = -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya);
@@ -116,12 +116,12 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
     const float dtdx = (float)(hx * (double)P.scale * (double)(te - tw));
     const float dtdy = (float)(hy * (double)P.scale * (double)(tn - ts));
     if (OP == ST_QVEC_X) {
-      const float dugdx = (float)(hx * (double)(ue - uw));
-      const float dvgdx = (float)(hx * (double)(ve - vw));
+      const float dugdx = half_prod(P.xmapr[p], ue - uw);
+      const float dvgdx = half_prod(P.xmapr[p], ve - vw);
       o.o0 = P.scale2 * (dugdx * dtdx + dvgdx * dtdy);
     } else {
-      const float dugdy = (float)(hy * (double)(un - us));
-      const float dvgdy = (float)(hy * (double)(vn - vs));
+      const float dugdy = half_prod(P.ymapr[p], un - us);
+      const float dvgdy = half_prod(P.ymapr[p], vn - vs);
       o.o0 = P.scale2 * (dugdy * dtdx + dvgdy * dtdy);
     }
     return true;
@@ -131,14 +131,14 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
     const float w = f[p - 1], e = f[p + 1];
     if (CHECK && !(all || (is_def(w, undef) && is_def(e, undef))))
       return false;
-    o.o0 = (float)(0.5 * (double)P.xmapr[p] * (double)(e - w));
+    o.o0 = half_prod(P.xmapr[p], e - w);
     return true;
   }
   if (OP == ST_GRAD_Y) { // :2027-2028
     const float s = f[p - nx], n = f[p + nx];
     if (CHECK && !(all || (is_def(s, undef) && is_def(n, undef))))
       return false;
-    o.o0 = (float)(0.5 * (double)P.ymapr[p] * (double)(n - s));
+    o.o0 = half_prod(P.ymapr[p], n - s);
     return true;
   }
   const float s = f[p - nx], w = f[p - 1], e = f[p + 1], n = f[p + nx];
@@ -162,8 +162,8 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
   if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef)))) // :2039, :660, :693, :1534
     return false;
   if (OP == ST_GRAD_ABS) { // :2040-2042
-    const float dfdx = (float)(0.5 * (double)P.xmapr[p] * (double)(e - w));
-    const float dfdy = (float)(0.5 * (double)P.ymapr[p] * (double)(n - s));
+    const float dfdx = half_prod(P.xmapr[p], e - w);
+    const float dfdy = half_prod(P.ymapr[p], n - s);
     o.o0 = absval(dfdx, dfdy);
   } else if (OP == ST_GWIND_X) { // :661
     o.o0 = (float)(-0.5 * (double)P.ymapr[p] * (double)(n - s) * (double)MIFC_K_G / (double)P.fcoriolis[p]);

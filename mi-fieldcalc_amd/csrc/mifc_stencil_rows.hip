@@ -86,13 +86,13 @@ __device__ __forceinline__ bool scalar_cell(bool all, float undef, float w, floa
   if (OP == ST_GRAD_X) { // :2015-2016
     if (CHECK && !(all || (is_def(w, undef) && is_def(e, undef))))
       return false;
-    o0 = (float)(0.5 * (double)xm * (double)(e - w));
+    o0 = half_prod(xm, e - w);
     return true;
   }
   if (OP == ST_GRAD_Y) { // :2027-2028
     if (CHECK && !(all || (is_def(s, undef) && is_def(n, undef))))
       return false;
-    o0 = (float)(0.5 * (double)ym * (double)(n - s));
+    o0 = half_prod(ym, n - s);
     return true;
   }
   if (OP == ST_GRAD_LAP || OP == ST_GVORT) {
@@ -114,8 +114,8 @@ __device__ __forceinline__ bool scalar_cell(bool all, float undef, float w, floa
   if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef)))) // :2039, :660, :693, :1534
     return false;
   if (OP == ST_GRAD_ABS) { // :2040-2042
-    const float dfdx = (float)(0.5 * (double)xm * (double)(e - w));
-    const float dfdy = (float)(0.5 * (double)ym * (double)(n - s));
+    const float dfdx = half_prod(xm, e - w);
+    const float dfdy = half_prod(ym, n - s);
     o0 = absval(dfdx, dfdy);
   } else if (OP == ST_GWIND_X) { // :661
     o0 = (float)(-0.5 * (double)ym * (double)(n - s) * (double)MIFC_K_G / (double)fc);

@@ -423,11 +423,10 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
           zv[k] = 0.f;
           zd[k] = 0.f;
           if (JAC) { // :2445-2449: four float-rounded partials, float combination
-            const double hx = 0.5 * (double)xm4[k], hy = 0.5 * (double)ym4[k];
-            const float df1dx = (float)(hx * (double)(ue - uw));
-            const float df1dy = (float)(hy * (double)dudy);
-            const float df2dx = (float)(hx * (double)(ve - vw));
-            const float df2dy = (float)(hy * (double)dvdy);
+            const float df1dx = half_prod(xm4[k], ue - uw);
+            const float df1dy = half_prod(ym4[k], dudy);
+            const float df2dx = half_prod(xm4[k], ve - vw);
+            const float df2dy = half_prod(ym4[k], dvdy);
             zv[k] = ok ? (df1dx * df2dy - df1dy * df2dx) : undef;
           } else if (WANT_V)
             zv[k] = ok ? (ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, dudy, fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, dudy)) : undef;
@@ -559,11 +558,10 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
     zv[k] = 0.f;
     zd[k] = 0.f;
     if (JAC) { // :2445-2449: four float-rounded partials, float combination (u = field1, v = field2)
-      const double hx = 0.5 * (double)xm4[k], hy = 0.5 * (double)ym4[k];
-      const float df1dx = (float)(hx * (double)(ue - uw));
-      const float df1dy = (float)(hy * (double)(un[k] - us[k]));
-      const float df2dx = (float)(hx * (double)(ve - vw));
-      const float df2dy = (float)(hy * (double)(vn[k] - vs[k]));
+      const float df1dx = half_prod(xm4[k], ue - uw);
+      const float df1dy = half_prod(ym4[k], un[k] - us[k]);
+      const float df2dx = half_prod(xm4[k], ve - vw);
+      const float df2dy = half_prod(ym4[k], vn[k] - vs[k]);
       zv[k] = ok ? (df1dx * df2dy - df1dy * df2dx) : undef;
     } else if (WANT_V)
       zv[k] = ok ? (ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k])) : undef;

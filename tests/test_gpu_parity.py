@@ -831,3 +831,32 @@ def test_shapiro_levels_in_place(gpu_ctx, oracle):
     for l in range(nlev):
         ok, e, _ = oracle.call("shapiro2_filter", nx, ny, z[l], fdefined=int(flags[l]))
         assert cases.same_bits(dz[l].cpu().numpy(), e, nan_payload=False), l
+
+
+def test_winddir_extension(gpu_ctx):
+    """EXTENSION, no reference oracle: BASELINE.json names "wind direction from u/v", the
+    reference has no such function.  Pinned against its own definition only -- the meteorological direction the
+    wind blows from, dd = 270 - atan2(v, u) * 180 / pi in [0, 360), calm -> 0 -- restated here in float64."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny = 1440, 90
+    u, v = synth.wind(nx, ny, 4711)
+    u[0, :8] = [0.0, 0.0, 5.0, -5.0, 3.0, -3.0, 0.0, 1e-20]
+    v[0, :8] = [0.0, 5.0, 0.0, 0.0, 3.0, -3.0, -5.0, -1e-20]
+    expect = np.mod(270.0 - np.degrees(np.arctan2(v.astype(np.float64), u.astype(np.float64))), 360.0)
+    expect[(u == 0) & (v == 0)] = 0.0
+    for device in (False, True):
+        a = [torch.from_numpy(x).cuda() for x in (u, v)] if device else [u, v]
+        dd, flag = gpu_ctx.winddir(*a, fdefined=ALL)
+        dd = dd.cpu().numpy() if device else dd
+        assert flag == ALL and dd.min() >= 0.0 and dd.max() < 360.0
+        err = np.abs(dd.astype(np.float64) - expect)
+        err = np.minimum(err, 360.0 - err)  # 359.99999 vs 0.00001
+        assert err.max() < 2e-3, err.max()
+        assert list(dd[0, :7]) == [0.0, 180.0, 270.0, 90.0, 225.0, 45.0, 0.0]  # calm, from S, from W, from E, from SW, from NE, from N
+    uu = synth.sprinkle_undef(u, 5, 0.01)
+    dd, flag = gpu_ctx.winddir(uu, v, fdefined=SOME)
+    bad = (uu == cases.UNDEF) | np.isnan(uu)
+    assert flag == SOME and np.all(dd[bad] == cases.UNDEF) and np.all(dd[~bad] != cases.UNDEF)

@@ -133,6 +133,12 @@ def main():
     add("fused ff+RH+theta (hybrid)", 28, 4 * n, lambda: ctx.hlevel_derived_levels(u, v, t, q, ps, a, b, fdef_wind=flags, fdef_thermo=flags,
                                                                                     out={"ff": out, "rh": out2, "theta": o_t.reshape(NLEV, NY, NX)}),
         "hlevelhum", [h["t"], h["q"], h["ps"], 12.5, 0.73, "kelvin", 1])
+    o3 = torch.empty_like(u)
+    add("fused ff+RH+theta+Td (hybrid, one launch)", 32, 4 * n,
+        lambda: ctx.hlevel_derived_batch(u, v, t, q, ps, a, b, temp=("", 3), hum=("", 1), hum2=("", 9), fdef_wind=flags, fdef_thermo=flags,
+                                         out={"ff": out, "hum": out2, "temp": o_t.reshape(NLEV, NY, NX), "hum2": o3}),
+        "hlevelhum", [h["t"], h["q"], h["ps"], 12.5, 0.73, "kelvin", 9])
+    del o3
     # ---- the rest of the stencil family, on the batch seen as one tall field
     xm_t, ym_t, fc_t = (x.repeat(NLEV, 1).contiguous() for x in (dxm, dym, dfc))
     ALLD = fc.ALL_DEFINED
@@ -163,6 +169,19 @@ def main():
     add("cvtemp c=1", 8, 0, lambda: ctx.cvtemp(tall(t), 1, fdefined=ALLD, out=o_t), "cvtemp", [h["t"], 1])
     add("fieldOPERfield +", 12, 0, lambda: ctx.fieldOPERfield(1, tall(t), tall(q), fdefined=ALLD, out=o_t), "fieldOPERfield", [1, h["t"], h["q"]])
     add("log10Field", 8, 0, lambda: ctx.log10Field(tall(t), fdefined=ALLD, out=o_t), "log10Field", [h["t"]])
+    add("expField", 8, 0, lambda: ctx.expField(tall(q), fdefined=ALLD, out=o_t), "expField", [h["q"]])
+    add("powerField ^0.37", 8, 0, lambda: ctx.powerField(tall(t), 0.37, fdefined=ALLD, out=o_t), "powerField", [h["t"], 0.37])
+    add("snow_in_cm", 16, 0, lambda: ctx.snow_in_cm(tall(q), tall(t), tall(t2), fdefined=ALLD, out=o_t), "snow_in_cm", [h["q"], h["t"], h["t"] - 20])
+    # ---- the f1 operators over the level batch with shared map factors (mifc_stencil_levels_ex)
+    pres = np.linspace(1000.0, 100.0, NLEV).astype(np.float32)
+    add("advection (level batch)", 16, 8 * n, lambda: ctx.stencil_levels_ex("advection", z, u, v, dxm, dym, scalar=1.0, fdefined=flags, out0=out), "advection",
+        [h["z"], h["u"], h["v"], xm, ym, 1.0])
+    add("thermalFrontParameter (level batch)", 8, 8 * n, lambda: ctx.stencil_levels_ex("thermalFrontParameter", t, xmapr=dxm, ymapr=dym, fdefined=flags, out0=out),
+        "thermalFrontParameter", [h["t"], xm, ym])
+    add("plevelqvector c=1 (level batch)", 12, 12 * n,
+        lambda: ctx.stencil_levels_ex("plevelqvector", z, t, None, dxm, dym, dfc, level_scalars=pres, compute=1, fdefined=flags, out0=out), "plevelqvector",
+        [h["z"], h["t"], xm, ym, fcor, 500.0, 1])
+    add("shapiro2_filter (level batch)", 8, 0, lambda: ctx.stencil_levels_ex("shapiro2_filter", z, fdefined=flags, out0=out), "shapiro2_filter", [h["z"]])
     # ---- 8f-4: reductions over the batch's levels taken as ensemble members of one 1440x720 field
     nm = min(NLEV, 51)
     # 51 members are 211 MB -- they would sit in the 256 MB Infinity Cache between calls: every call takes the
