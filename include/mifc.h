@@ -70,6 +70,11 @@ const char* mifc_last_error(const mifc_ctx* ctx);
 int mifc_set_stream(mifc_ctx* ctx, void* hip_stream);
 int mifc_use_own_stream(mifc_ctx* ctx);
 int mifc_synchronize(mifc_ctx* ctx);
+/* Always returns 0 and leaves "<what>: not built on the GPU (...)" in mifc_last_error(): what the
+ * source-compatible C++ API calls for the reference functions outside the hot-path scope
+ * (neighbourFunctions, neighbourProbFunctions, vesselIcingModStall, vesselIcingMincog), so that
+ * their `false` can be told from an argument-validation failure. */
+int mifc_not_built(mifc_ctx* ctx, const char* what);
 /* The library's tuning / diagnostic environment variables (MIFC_*: which of several
  * equivalent kernel forms runs; none changes a result) are read when a context is
  * created, never on a call path.  Re-read them (tests, A/B tools). */

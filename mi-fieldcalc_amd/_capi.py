@@ -38,6 +38,7 @@ SIGNATURES = {
     "mifc_use_own_stream": ("i", ["ctx"]),
     "mifc_synchronize": ("i", ["ctx"]),
     "mifc_reload_env": ("i", ["ctx"]),
+    "mifc_not_built": ("i", ["ctx", "s"]),
     "mifc_device_alloc": ("p", ["ctx", "z"]),
     "mifc_device_free": ("i", ["ctx", "p"]),
     "mifc_copy_to_device": ("i", ["ctx", "p", "p", "z"]),

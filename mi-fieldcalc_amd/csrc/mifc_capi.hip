@@ -495,6 +495,13 @@ int mifc_use_own_stream(mifc_ctx* c)
   return switch_stream(c, c->own_stream);
 }
 
+int mifc_not_built(mifc_ctx* c, const char* what)
+{
+  if (c)
+    c->err = std::string(what ? what : "?") + ": not built on the GPU (outside the hot-path scope; there is no CPU fallback)";
+  return 0;
+}
+
 int mifc_synchronize(mifc_ctx* c)
 {
   if (!c)

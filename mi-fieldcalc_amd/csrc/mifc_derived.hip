@@ -122,13 +122,14 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
   const float* __restrict__ ph = P.h + base;
   const float* __restrict__ ps = P.ps;
 
-  const int n4 = P.n >> 2;
-  const int stride = gridDim.x * blockDim.x;
+  // unsigned 32-bit cell-group indices: base pointer in SGPRs + zero-extended lane offset (saddr addressing)
+  const unsigned n4 = (unsigned)P.n >> 2;
+  const unsigned stride = gridDim.x * blockDim.x;
   const v4f zero = {0.f, 0.f, 0.f, 0.f};
 
-  auto load = [&](int q) -> Trip {
+  auto load = [&](unsigned q) -> Trip {
     Trip r;
-    const size_t o = (size_t)q * 4;
+    const unsigned o = q * 4u;
     r.u = want_ff ? *reinterpret_cast<const v4f*>(pu + o) : zero;
     r.v = want_ff ? *reinterpret_cast<const v4f*>(pv + o) : zero;
     r.t = thermo ? *reinterpret_cast<const v4f*>(pt + o) : zero;
@@ -137,8 +138,12 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
     return r;
   };
 
-  auto compute = [&](int q, const Trip& in) {
-    const size_t o = base + (size_t)q * 4;
+  float* __restrict__ off = P.ff ? P.ff + base : nullptr;
+  float* __restrict__ otemp = P.temp ? P.temp + base : nullptr;
+  float* __restrict__ ohum = P.hum ? P.hum + base : nullptr;
+  float* __restrict__ otd = P.td ? P.td + base : nullptr;
+  auto compute = [&](unsigned q, const Trip& in) {
+    const unsigned o = q * 4u;
     if (want_ff) { // vectorabs :1831-1837
       float r[4];
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
           bad_ff += 1;
         }
       }
-      st4(P.ff + o, r);
+      st4(off + o, r);
     }
     if (thermo) {
       float rt[4], rh[4], rd[4];
@@ -201,29 +206,29 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
         }
       }
       if (want_t)
-        st4(P.temp + o, rt);
+        st4(otemp + o, rt);
       if (want_h)
-        st4(P.hum + o, rh);
+        st4(ohum + o, rh);
       if (want_d)
-        st4(P.td + o, rd);
+        st4(otd + o, rd);
     }
   };
 
   // two trips per iteration: the loads of the next trip are in flight while this one is computed
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
   if (!PIPE) {
     for (; q < n4; q += stride)
       compute(q, load(q));
   } else if (q < n4) {
     Trip cur = load(q);
     for (;;) {
-      const int q1 = q + stride;
+      const unsigned q1 = q + stride;
       const bool more1 = q1 < n4;
       Trip nxt = load(more1 ? q1 : q);
       compute(q, cur);
       if (!more1)
         break;
-      const int q2 = q1 + stride;
+      const unsigned q2 = q1 + stride;
       const bool more2 = q2 < n4;
       cur = load(more2 ? q2 : q1);
       compute(q1, nxt);

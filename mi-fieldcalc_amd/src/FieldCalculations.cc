@@ -337,26 +337,27 @@ bool vesselIcingMertins(int nx, int ny, const float* airtemp, const float* seate
   MIFC_FORWARD(mifc_vesselIcingMertins(context(), nx, ny, airtemp, seatemp, u, v, sal, aice, icing, f.ptr(), undef, MIFC_MEM_HOST));
 }
 
-// Not built on the GPU yet (FieldCalculationsVesselIcing.cc:182, :677): "false", like any other failure.
+// Not built on the GPU (FieldCalculationsVesselIcing.cc:182, :677; out of the hot-path scope): false, and
+// last_error() says why -- an argument-validation failure leaves last_error() empty.
 bool vesselIcingModStall(int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                          const float*, const float*, const float*, const float, const float, const float, const float, float*, ValuesDefined&, float)
 {
-  return false;
+  return mifc_not_built(context(), "vesselIcingModStall") != 0;
 }
 bool vesselIcingMincog(int, int, const float*, const float*, const float*, const float*, const float*, const float*, const float*, const float*,
                        const float*, const float*, const float*, const float, const float, const float, const float, const int, float*, ValuesDefined&,
                        float)
 {
-  return false;
+  return mifc_not_built(context(), "vesselIcingMincog") != 0;
 }
 
 bool neighbourProbFunctions(int, int, const float*, const std::vector<float>&, int, float*, ValuesDefined&, float)
 {
-  return false; // FieldCalculations.cc:2862, not built
+  return mifc_not_built(context(), "neighbourProbFunctions") != 0; // FieldCalculations.cc:2862
 }
 bool neighbourFunctions(int, int, const float*, const std::vector<float>&, int, float*, ValuesDefined&, float)
 {
-  return false; // FieldCalculations.cc:2955, not built
+  return mifc_not_built(context(), "neighbourFunctions") != 0; // FieldCalculations.cc:2955
 }
 
 #define MIFC_FORWARD_VOID(call) \

@@ -83,6 +83,7 @@ CXX_CALLER = r"""
 #include <mi_fieldcalc/math_util.h>
 #include <mi_fieldcalc/mi_fieldcalc_version.h>
 #include <cstdio>
+#include <string>
 #include <vector>
 int main()
 {
@@ -124,6 +125,15 @@ int main()
   ValuesDefined f7 = ALL_DEFINED;
   fieldcalc::maxvalueFieldConst(nx, ny, u.data(), 3.5f, out.data(), f7, UNDEF); // a void function of the reference
   std::printf("%d %g %d %g %d %g %d %g %g\n", ok4, (double)sum1, ok5, (double)sum2, ok6, (double)mean, ok7, (double)cls, (double)out[7]);
+  // a reference function that is outside the hot-path scope: false, and last_error() says so
+  // (an argument-validation failure -- the too-small relvort above -- leaves it empty)
+  ValuesDefined f8 = ALL_DEFINED;
+  const bool ok8 = fieldcalc::neighbourFunctions(nx, ny, u.data(), limits, 1, out.data(), f8, UNDEF);
+  const std::string why = fieldcalc::last_error();
+  ValuesDefined f9 = SOME_DEFINED;
+  fieldcalc::relvort(2, 2, u.data(), v.data(), xm.data(), ym.data(), out.data(), f9, fieldUndef);
+  const std::string why2 = fieldcalc::last_error();
+  std::printf("%d|%s|%s\n", ok8, why.c_str(), why2.c_str());
   return 0;
 }
 """
@@ -154,6 +164,10 @@ def test_cxx_header_is_source_compatible(built, tmp_path):
         assert more == ["1", "7", "1", "10", "1", "3.33333", "1", "1", "3.5"], more
     else:
         assert more[0] == more[2] == more[4] == more[6] == "0"
+    ok8, why, why2 = res.stdout.splitlines()[2].split("|")
+    assert ok8 == "0"
+    if have_gpu:
+        assert "neighbourFunctions: not built on the GPU" in why and why2 == ""
 
 
 REF_PYBIND_SRC = "/root/reference/python/py_mi_fieldcalc.cc"

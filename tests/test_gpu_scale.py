@@ -623,3 +623,53 @@ def test_zz_report_cells_beyond_strict_relative_tolerance():
         with open(os.path.join(out, "strict_tolerance_report.txt"), "w") as f:
             f.write(text + "\n")
     assert rows
+
+
+# ------------------------------------------------------------------ config 1: 256 x 256 through the unchanged C++ signature
+CONFIG1_CALLER = r"""
+// BASELINE.json config 1: wind speed from u/v on one 256x256 float32 field through the reference's own C++
+// signature (host pointers, ValuesDefined&), exactly as an existing caller is written.
+#include <mi_fieldcalc/FieldCalculations.h>
+#include <cstdio>
+#include <vector>
+int main(int argc, char** argv)
+{
+  const int nx = 256, ny = 256;
+  std::vector<float> u(nx * ny), v(nx * ny), ff(nx * ny, -1.f);
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f || std::fread(u.data(), 4, u.size(), f) != u.size() || std::fread(v.data(), 4, v.size(), f) != v.size())
+    return 2;
+  std::fclose(f);
+  miutil::ValuesDefined fDefined = argv[3][0] == 'A' ? miutil::ALL_DEFINED : miutil::SOME_DEFINED;
+  if (!miutil::fieldcalc::vectorabs(nx, ny, u.data(), v.data(), ff.data(), fDefined, miutil::UNDEF))
+    return 3;
+  f = std::fopen(argv[2], "wb");
+  std::fwrite(ff.data(), 4, ff.size(), f);
+  std::fclose(f);
+  std::printf("%d\n", (int)fDefined);
+  return 0;
+}
+"""
+
+
+@pytest.mark.parametrize("mode", ["all", "some"])
+def test_config1_vectorabs_256x256_through_the_cxx_signature(oracle, tmp_path, mode):
+    import mi_fieldcalc_amd.synth as synth
+
+    nx = ny = 256
+    u, v = synth.wind(nx, ny, 0x5EED0000 + 1000)
+    flag = ALL
+    if mode == "some":
+        u, flag = synth.sprinkle_undef(u, 3, 0.01), SOME
+    src, exe, fin, fout = tmp_path / "c1.cc", tmp_path / "c1", tmp_path / "in.bin", tmp_path / "out.bin"
+    src.write_text(CONFIG1_CALLER)
+    inc, libdir = os.path.join(ROOT, "mi-fieldcalc_amd", "include"), os.path.join(ROOT, "mi-fieldcalc_amd")
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-lmi-fieldcalc", "-lmifc", "-Wl,-rpath," + libdir],
+                   check=True)
+    with open(fin, "wb") as f:
+        f.write(u.tobytes())
+        f.write(v.tobytes())
+    res = subprocess.run([str(exe), str(fin), str(fout), "A" if flag == ALL else "S"], capture_output=True, text=True, check=True)
+    got = np.fromfile(fout, np.float32).reshape(ny, nx)
+    ok, e, f_e = oracle.call("vectorabs", nx, ny, u, v, fdefined=flag)
+    assert ok and _bits_equal(got, e) and int(res.stdout.split()[0]) == f_e

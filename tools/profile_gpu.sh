@@ -8,7 +8,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+CMD="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-verify --no-check-variant"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"

@@ -1,24 +1,37 @@
 #!/bin/bash
 # Everything profiles/README.md quotes for a round, on ONE box in one gpurun call:
-#   bash tools/round_end_measure.sh r01   (outputs under gpurun_out/)
+#   bash tools/round_end_measure.sh r02   (outputs under gpurun_out/<tag>_end/)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+O=gpurun_out/${TAG}_end
+mkdir -p "$O"
 export TMPDIR=/tmp
-python3 bench.py --steps 20 --warmup 3 > gpurun_out/bench_n1.json 2> gpurun_out/bench_n1.err
-echo "bench rc=$?"; cat gpurun_out/bench_n1.json
-python3 bench.py --steps 20 --warmup 3 --check --no-cpu-baseline > gpurun_out/bench_n1_check.json 2>/dev/null
-echo "bench --check rc=$?"
-python3 tools/sweep_vortdiv.py "R=6" "R=8" "R=6,XS=1" > gpurun_out/sweep_same_device_as_bench.txt 2>&1
+python3 bench.py --steps 20 --warmup 5 > "$O/bench_n1.json" 2> "$O/bench_n1.err"
+echo "bench rc=$?"; cat "$O/bench_n1.json"
+echo "# five consecutive processes of 'python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline' on ONE box, same binary" > "$O/bench_repeat.txt"
+echo "# Mcells/s  ms_per_step(wall)  kernel_ms_avg(HIP events)  roofline.frac  tested-variant frac  verified" >> "$O/bench_repeat.txt"
+for i in 1 2 3 4 5; do
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'], d.get('check_variant',{}).get('roofline_frac'), d['verified'])" >> "$O/bench_repeat.txt"
+done
+cat "$O/bench_repeat.txt"
+python3 tools/sweep_vortdiv.py "R=8" "R=8,XS=1" "R=8,XL=1" > "$O/sweep_same_device_as_bench.txt" 2>&1
 echo "sweep rc=$?"
-bash tools/profile_gpu.sh "$TAG" > gpurun_out/profile_gpu.log 2>&1
-echo "profile rc=$?"; tail -25 gpurun_out/profile_gpu.log
-python3 tools/bench_ops.py 137 > gpurun_out/per_operator_table.txt 2>&1
+bash tools/profile_gpu.sh "$TAG" > "$O/profile_gpu.log" 2>&1
+echo "profile rc=$?"; tail -25 "$O/profile_gpu.log"
+bash tools/profile_derived.sh "$TAG" > "$O/profile_derived.log" 2>&1
+echo "profile derived rc=$?"; tail -25 "$O/profile_derived.log"
+python3 tools/bench_derived.py 137 > "$O/bench_derived.txt" 2>&1
+echo "derived rc=$?"
+python3 tools/bench_f1_levels.py 137 > "$O/bench_f1_levels.txt" 2>&1
+echo "f1 rc=$?"
+python3 tools/bench_ops.py 137 > "$O/per_operator_table.txt" 2>&1
 echo "ops rc=$?"
-# the two stencil-of-a-stencil operators: one fused launch vs the multi-pass path, same box
-{ echo "# fused (default)"; BENCH_OPS_ONLY="thermalFront|qvector" python3 tools/bench_ops.py 137 | tail -n 3;
-  echo "# MIFC_FUSED2=0 (multi-pass)"; MIFC_FUSED2=0 BENCH_OPS_ONLY="thermalFront|qvector" python3 tools/bench_ops.py 137 | tail -n 3; } > gpurun_out/fused2_ops.txt 2>&1
-echo "fused2 rc=$?"
-python3 tools/bench_hostpath.py > gpurun_out/hostpath_after.jsonl 2>&1
+python3 tools/bench_hostpath.py > "$O/hostpath.jsonl" 2>&1
 echo "hostpath rc=$?"
-python3 tools/bench_configs.py > gpurun_out/other_configs.jsonl 2>&1
+python3 tools/bench_configs.py > "$O/other_configs.jsonl" 2>&1
 echo "configs rc=$?"
+# the N-rank drivers rehearsed with two ranks sharing this box's GPU (gloo carries the halo rows through the host)
+for C in "--config 4 --check" "--config 4 --all-defined --check" "--config 5 --members 6 --check"; do
+  MIFC_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29711 tools/bench_multigpu.py $C 2>/dev/null | grep "^{" >> "$O/multigpu_gloo_rehearsal.jsonl"
+done
+echo "multigpu rehearsal rc=$?"; cat "$O/multigpu_gloo_rehearsal.jsonl"

@@ -23,6 +23,7 @@ def find(root, pattern):
 
 def main():
     root = sys.argv[1]
+    kernel = sys.argv[2] if len(sys.argv) > 2 else "vortdiv_rows_kernel"
     # ---- kernel stats
     for f in find(os.path.join(root, "trace"), "*kernel_stats.csv"):
         print("== kernel stats:", os.path.relpath(f, root))
@@ -50,12 +51,12 @@ def main():
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 kn = r.get("Kernel_Name", "")
-                if "vortdiv_rows_kernel" not in kn:
+                if kernel not in kn:
                     continue
                 per_counter[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 regs = {k: r.get(k) for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Grid_Size", "Workgroup_Size")}
     if per_counter:
-        print("== PMC, average per dispatch of vortdiv_rows_kernel")
+        print("== PMC, average per dispatch of " + kernel)
         avg = {k: sum(v) / len(v) for k, v in per_counter.items()}
         for k in sorted(avg):
             print("  %-28s %.6g  (n=%d)" % (k, avg[k], len(per_counter[k])))
