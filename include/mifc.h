@@ -360,24 +360,25 @@ int mifc_hlevel_derived_levels_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, 
  *   hum  = hlevelhum(t, h, ps, a_l, b_l, hum_unit, hum_compute)          (.cc:1145; compute 1..12)
  *   hum2 = hlevelhum(t, h, ps, a_l, b_l, hum2_unit, hum2_compute)        a second variant of the SAME inputs,
  *          e.g. hum = RH (compute 1) and hum2 = dew point (compute 9) from T and q
+ *   dd   = mifc_winddir(u, v)   EXTENSION, not a reference function (see above): wind direction
  * in ONE pass over u, v, t, h ([nlev][ny][nx]; h = specific humidity or RH as the variants demand; ps [ny][nx]
  * shared).  NULL outputs are skipped (their inputs are not read); unit / compute arguments of a skipped
  * output are ignored.  Results and flags per level are those of the per-level reference calls.  Returns 0
  * where one of those calls would return false (bad (a, b) pair .cc:298, compute out of range) and for
  * temp_compute outside 1..5 (the reference leaves such cells unwritten, .cc:1080-1090).
  * fdef_wind / fdef_thermo: host int[nlev] input states of (u, v) and of (t, h, ps); fdef_ff, fdef_temp,
- * fdef_hum, fdef_hum2: host int[nlev] results (may be NULL). */
+ * fdef_hum, fdef_hum2, fdef_dd: host int[nlev] results (may be NULL). */
 int mifc_hlevel_derived_batch(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* h,
                               const float* ps, const float* alevel, const float* blevel, float* ff, float* temp, const char* temp_unit,
                               int temp_compute, float* hum, const char* hum_unit, int hum_compute, float* hum2, const char* hum2_unit,
-                              int hum2_compute, const int* fdef_wind, const int* fdef_thermo, int* fdef_ff, int* fdef_temp, int* fdef_hum,
-                              int* fdef_hum2, float undef, int memkind);
-/* Asynchronous, device pointers only.  n_undefined_dev: device u64[4*nlev] laid out
- * [ff | temp | hum | hum2], zeroed by the call; classify against nx*ny. */
+                              int hum2_compute, float* dd, const int* fdef_wind, const int* fdef_thermo, int* fdef_ff, int* fdef_temp,
+                              int* fdef_hum, int* fdef_hum2, int* fdef_dd, float undef, int memkind);
+/* Asynchronous, device pointers only.  n_undefined_dev: device u64[5*nlev] laid out
+ * [ff | temp | hum | hum2 | dd], zeroed by the call; classify against nx*ny. */
 int mifc_hlevel_derived_batch_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* h,
                                       const float* ps, const float* alevel, const float* blevel, float* ff, float* temp, const char* temp_unit,
                                       int temp_compute, float* hum, const char* hum_unit, int hum_compute, float* hum2, const char* hum2_unit,
-                                      int hum2_compute, const int* fdef_wind, const int* fdef_thermo, float undef,
+                                      int hum2_compute, float* dd, const int* fdef_wind, const int* fdef_thermo, float undef,
                                       unsigned long long* n_undefined_dev);
 
 /* ---- horizontally decomposed single field (row slabs) -------------------- */

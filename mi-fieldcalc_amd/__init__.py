@@ -651,25 +651,26 @@ class Context:
         res = {k: (out[k] if _is_torch(out[k]) else o[k].keep) for k in want}
         return res, {k: fo[k] for k in want}
 
-    def hlevel_derived_batch(self, u, v, t, h, ps, alevel, blevel, temp=None, hum=None, hum2=None, ff=True, fdef_wind=None, fdef_thermo=None,
-                             undef=UNDEF, out=None, enqueue_counts=None):
+    def hlevel_derived_batch(self, u, v, t, h, ps, alevel, blevel, temp=None, hum=None, hum2=None, ff=True, dd=False, fdef_wind=None,
+                             fdef_thermo=None, undef=UNDEF, out=None, enqueue_counts=None):
         """The general fused derived batch (mifc_hlevel_derived_batch): per level any of
           ff   = vectorabs(u, v)                         (ff=True)
           temp = hleveltemp(t, ps, a, b, unit, compute)  (temp=(unit, compute))
           hum  = hlevelhum(t, h, ps, a, b, unit, compute)   (hum=(unit, compute))
           hum2 = a second hlevelhum variant of the same inputs (hum2=(unit, compute))
+          dd   = wind direction from u, v (dd=True) -- EXTENSION, not a reference function
         u, v, t, h: (nlev, ny, nx); ps: (ny, nx).  out: optional dict of preallocated outputs.
-        Returns ({name: array}, {name: flags}) or None.  With enqueue_counts (int64 CUDA tensor[4*nlev]) the call is
-        asynchronous on device tensors and returns the outputs only (counts: ff | temp | hum | hum2)."""
+        Returns ({name: array}, {name: flags}) or None.  With enqueue_counts (int64 CUDA tensor[5*nlev]) the call is
+        asynchronous on device tensors and returns the outputs only (counts: ff | temp | hum | hum2 | dd)."""
         ref = next(x for x in (u, t) if x is not None)
         nlev, ny, nx = _Arg(ref).shape
-        names = [k for k, w in (("ff", ff), ("temp", temp), ("hum", hum), ("hum2", hum2)) if w]
+        names = [k for k, w in (("ff", ff), ("temp", temp), ("hum", hum), ("hum2", hum2), ("dd", dd)) if w]
         out = dict(out or {})
         for k in names:
             if out.get(k) is None:
                 out[k] = _empty_like(ref)
         a = {k: _Arg(x, allow_none=True) for k, x in dict(u=u, v=v, t=t, h=h, ps=ps).items()}
-        o = {k: _Arg(out.get(k) if k in names else None, allow_none=True, output=True) for k in ("ff", "temp", "hum", "hum2")}
+        o = {k: _Arg(out.get(k) if k in names else None, allow_none=True, output=True) for k in ("ff", "temp", "hum", "hum2", "dd")}
         if not _same_shape([a[k] for k in ("u", "v", "t", "h")] + list(o.values()), (nlev, ny, nx)) or not _same_shape([a["ps"]], (ny, nx)):
             raise ValueError("level fields must be (nlev, ny, nx) and ps (ny, nx)")
         mk = _memkind(list(a.values()) + list(o.values()), self.device)
@@ -682,14 +683,14 @@ class Context:
         comp = lambda w: int(w[1]) if w else 0
         common = [nx, ny, nlev, a["u"].addr, a["v"].addr, a["t"].addr, a["h"].addr, a["ps"].addr, al.ctypes.data, bl.ctypes.data,
                   o["ff"].addr, o["temp"].addr, unit(temp), comp(temp), o["hum"].addr, unit(hum), comp(hum), o["hum2"].addr, unit(hum2), comp(hum2),
-                  fw.ctypes.data, ft.ctypes.data]
+                  o["dd"].addr, fw.ctypes.data, ft.ctypes.data]
         if enqueue_counts is not None:
             if mk != MEM_DEVICE:
                 raise ValueError("the *_enqueue calls take device tensors only")
             rc = self._call("mifc_hlevel_derived_batch_enqueue", common + [float(undef), enqueue_counts.data_ptr()])
             return {k: out[k] for k in names} if rc else None
-        fo = {k: np.full(nlev, -1, np.int32) for k in ("ff", "temp", "hum", "hum2")}
-        rc = self._call("mifc_hlevel_derived_batch", common + [fo[k].ctypes.data for k in ("ff", "temp", "hum", "hum2")] + [float(undef), mk])
+        fo = {k: np.full(nlev, -1, np.int32) for k in ("ff", "temp", "hum", "hum2", "dd")}
+        rc = self._call("mifc_hlevel_derived_batch", common + [fo[k].ctypes.data for k in ("ff", "temp", "hum", "hum2", "dd")] + [float(undef), mk])
         if not rc:
             return None
         res = {k: (out[k] if _is_torch(out[k]) else o[k].keep) for k in names}

@@ -137,12 +137,12 @@ SIGNATURES = {
     ),
     "mifc_hlevel_derived_batch": (
         "i",
-        ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "s", "i", "p", "s", "i", "p", "s", "i", "pi", "pi", "pi", "pi", "pi", "pi",
-         "f", "i"],
+        ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "s", "i", "p", "s", "i", "p", "s", "i", "p", "pi", "pi", "pi", "pi", "pi",
+         "pi", "pi", "f", "i"],
     ),
     "mifc_hlevel_derived_batch_enqueue": (
         "i",
-        ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "s", "i", "p", "s", "i", "p", "s", "i", "pi", "pi", "f", "pu"],
+        ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "p", "p", "s", "i", "p", "s", "i", "p", "s", "i", "p", "pi", "pi", "f", "pu"],
     ),
     "mifc_vortdiv_slab_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu"]),
     "mifc_vortdiv_slab_rows_enqueue": ("i", ["ctx", "i", "i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu", "i"]),

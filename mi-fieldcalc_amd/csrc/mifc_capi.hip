@@ -77,13 +77,13 @@ bool ensure_levels(mifc_ctx* c, size_t nlev)
     cap *= 2;
   if ((e = hipMalloc((void**)&c->d_flags, 2 * cap)) != hipSuccess)
     return fail(c, "hipMalloc(flags)", e);
-  if ((e = hipMalloc((void**)&c->d_counts, 4 * cap * sizeof(u64))) != hipSuccess)
+  if ((e = hipMalloc((void**)&c->d_counts, 5 * cap * sizeof(u64))) != hipSuccess)
     return fail(c, "hipMalloc(counts)", e);
   if ((e = hipMalloc((void**)&c->d_ab, 2 * cap * sizeof(float))) != hipSuccess)
     return fail(c, "hipMalloc(ab)", e);
   if ((e = hipMalloc((void**)&c->d_levels, cap * sizeof(int))) != hipSuccess)
     return fail(c, "hipMalloc(levels)", e);
-  if ((e = hipHostMalloc(&c->h_pinned, 4 * cap * sizeof(u64) + 2 * cap + 2 * cap * sizeof(float), hipHostMallocDefault)) != hipSuccess)
+  if ((e = hipHostMalloc(&c->h_pinned, 5 * cap * sizeof(u64) + 2 * cap + 2 * cap * sizeof(float), hipHostMallocDefault)) != hipSuccess)
     return fail(c, "hipHostMalloc", e);
   c->cap_lev = cap;
   return true;
@@ -124,11 +124,11 @@ u64* pinned_counts(mifc_ctx* c)
 }
 unsigned char* pinned_flags(mifc_ctx* c)
 {
-  return reinterpret_cast<unsigned char*>(c->h_pinned) + 4 * c->cap_lev * sizeof(u64);
+  return reinterpret_cast<unsigned char*>(c->h_pinned) + 5 * c->cap_lev * sizeof(u64);
 }
 float* pinned_ab(mifc_ctx* c)
 {
-  return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(c->h_pinned) + 4 * c->cap_lev * sizeof(u64) + 2 * c->cap_lev);
+  return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(c->h_pinned) + 5 * c->cap_lev * sizeof(u64) + 2 * c->cap_lev);
 }
 
 // Brings a field to the device if the caller handed a host pointer.
@@ -1355,7 +1355,7 @@ int mifc_stencil_levels_ex(mifc_ctx* c, int op, int nx, int ny, int nlev, const 
     F.undef = undef;
     F.counts = c->d_counts;
     F.level_stride = (long)n;
-    fused = fused && fused2_enabled() && mifc::fused2_supported(F) && n % 4 == 0 && 3 * (size_t)nlev <= 4 * c->cap_lev;
+    fused = fused && fused2_enabled() && mifc::fused2_supported(F) && n % 4 == 0 && 3 * (size_t)nlev <= 5 * c->cap_lev;
     if (fused) {
       if (!pinned_acquire(c))
         return 0;
@@ -1499,6 +1499,7 @@ struct DerivedRequest
   float *ff, *temp, *hum, *hum2;
   const char *temp_unit, *hum_unit, *hum2_unit;
   int temp_compute, hum_compute, hum2_compute;
+  float* dd; // extension output: wind direction
 };
 
 // hlevelhum's remaps (:1168-1182) for one humidity output; false = the reference returns false
@@ -1516,15 +1517,16 @@ bool derived_hum_variant(const char* unit, int compute, int* code, float* tdconv
 }
 
 // Validates like the per-level reference calls would, uploads the per-level scalars and launches (or,
-// with prepared_only, hands the parameters to the host pipeline).  counts_dev: u64[4 * nlev], ff | temp | hum | hum2.
+// with prepared_only, hands the parameters to the host pipeline).  counts_dev: u64[5 * nlev], ff | temp | hum | hum2 | dd.
 int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq, const int* fdef_wind, const int* fdef_thermo, float undef,
                    u64* counts_dev, mifc::DerivedParams* prepared_only = nullptr)
 {
   if (nlev < 1 || nx * ny <= 0)
     return 0;
-  if (!rq.ff && !rq.temp && !rq.hum && !rq.hum2)
+  if (!rq.ff && !rq.temp && !rq.hum && !rq.hum2 && !rq.dd)
     return 0;
   const bool thermo = rq.temp || rq.hum || rq.hum2;
+  const bool wind = rq.ff || rq.dd;
   mifc::DerivedParams P;
   std::memset(&P, 0, sizeof P);
   if (rq.temp) {
@@ -1563,17 +1565,19 @@ int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& 
   P.temp = rq.temp;
   P.hum = rq.hum;
   P.td = rq.hum2;
+  P.dd = rq.dd;
   P.undef = undef;
   P.cnt_ff = counts_dev;
   P.cnt_temp = counts_dev + nlev;
   P.cnt_hum = counts_dev + 2 * (size_t)nlev;
   P.cnt_td = counts_dev + 3 * (size_t)nlev;
+  P.cnt_dd = counts_dev + 4 * (size_t)nlev;
   bool every_all = true;
   if (nlev <= 8 && !prepared_only) {
     // small batch: per-level scalars travel in the kernel arguments
     P.n_inline = 1;
     for (int l = 0; l < nlev; ++l) {
-      const bool w = !rq.ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
+      const bool w = !wind || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
       const bool th = !thermo || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
       P.wind_inline[l] = w ? 1 : 0;
       P.thermo_inline[l] = th ? 1 : 0;
@@ -1586,7 +1590,7 @@ int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& 
       return 0;
     unsigned char* hf = pinned_flags(c);
     for (int l = 0; l < nlev; ++l) {
-      const bool w = !rq.ff || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
+      const bool w = !wind || (fdef_wind && fdef_wind[l] == MIFC_ALL_DEFINED);
       const bool th = !thermo || (fdef_thermo && fdef_thermo[l] == MIFC_ALL_DEFINED);
       hf[l] = w ? 1 : 0;
       hf[c->cap_lev + l] = th ? 1 : 0;
@@ -1607,7 +1611,7 @@ int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& 
     P.thermo_all_defined = c->d_flags + c->cap_lev;
   }
   P.every_level_all_defined = every_all ? 1 : 0;
-  MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 4 * sizeof(u64) * (size_t)nlev, c->stream));
+  MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 5 * sizeof(u64) * (size_t)nlev, c->stream));
   if (prepared_only) { // the caller launches chunk by chunk (host pipeline)
     *prepared_only = P;
   } else {
@@ -1618,7 +1622,8 @@ int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& 
   return 1;
 }
 
-void derived_flags(const u64* cnt, int nlev, size_t n, const DerivedRequest& rq, int* fdef_ff, int* fdef_temp, int* fdef_hum, int* fdef_hum2)
+void derived_flags(const u64* cnt, int nlev, size_t n, const DerivedRequest& rq, int* fdef_ff, int* fdef_temp, int* fdef_hum, int* fdef_hum2,
+                   int* fdef_dd)
 {
   for (int l = 0; l < nlev; ++l) {
     if (rq.ff && fdef_ff)
@@ -1629,11 +1634,13 @@ void derived_flags(const u64* cnt, int nlev, size_t n, const DerivedRequest& rq,
       fdef_hum[l] = mifc_classify(cnt[2 * (size_t)nlev + l], (u64)n);
     if (rq.hum2 && fdef_hum2)
       fdef_hum2[l] = mifc_classify(cnt[3 * (size_t)nlev + l], (u64)n);
+    if (rq.dd && fdef_dd)
+      fdef_dd[l] = mifc_classify(cnt[4 * (size_t)nlev + l], (u64)n);
   }
 }
 
 int derived_sync(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq0, const int* fdef_wind, const int* fdef_thermo, int* fdef_ff,
-                 int* fdef_temp, int* fdef_hum, int* fdef_hum2, float undef, int memkind)
+                 int* fdef_temp, int* fdef_hum, int* fdef_hum2, int* fdef_dd, float undef, int memkind)
 {
   if (nlev < 1 || nx * ny <= 0)
     return 0;
@@ -1644,9 +1651,11 @@ int derived_sync(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq
   const size_t n = (size_t)nx * ny, nb = n * (size_t)nlev;
   const bool thermo = rq0.temp || rq0.hum || rq0.hum2;
   const bool humid = rq0.hum || rq0.hum2;
+  const bool wind = rq0.ff || rq0.dd;
   DerivedRequest rq = rq0;
   bool ok = true;
-  if (memkind == MIFC_MEM_HOST && mifc::hostpipe_chunk_levels(n, nlev) > 0 && host_pipeline_enabled()) {
+  // (the chunked pipeline carries four outputs; a request with the wind direction on top is staged whole)
+  if (memkind == MIFC_MEM_HOST && mifc::hostpipe_chunk_levels(n, nlev) > 0 && host_pipeline_enabled() && !(rq0.dd && rq0.ff && rq0.temp && rq0.hum && rq0.hum2)) {
     // a large batch in host memory: chunks of levels stream through the device, copies
     // in both directions overlapping the kernels (mifc_hostpipe.h)
     if (!c->pipe && !(c->pipe = mifc::hostpipe_create(c->device))) {
@@ -1658,8 +1667,8 @@ int derived_sync(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq
       return 0;
     mifc::DerivedParams base;
     // the host pointers are placeholders that mark which fields take part; the chunk launcher substitutes device buffers
-    rq.u = rq0.ff ? rq0.u : nullptr;
-    rq.v = rq0.ff ? rq0.v : nullptr;
+    rq.u = wind ? rq0.u : nullptr;
+    rq.v = wind ? rq0.v : nullptr;
     rq.t = thermo ? rq0.t : nullptr;
     rq.h = humid ? rq0.h : nullptr;
     if (!derived_common(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, undef, c->d_counts, &base))
@@ -1667,7 +1676,7 @@ int derived_sync(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq
     MIFC_HIP(c, hipStreamSynchronize(c->stream)); // ps, flags, level coefficients, zeroed counters are in place
     const float* h_in[4];
     int slot_u = -1, slot_v = -1, slot_t = -1, slot_h = -1, n_in = 0;
-    if (rq0.ff) {
+    if (wind) {
       slot_u = n_in;
       h_in[n_in++] = rq0.u;
       slot_v = n_in;
@@ -1681,7 +1690,15 @@ int derived_sync(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq
       slot_h = n_in;
       h_in[n_in++] = rq0.h;
     }
-    float* h_out[4] = {rq0.ff, rq0.temp, rq0.hum, rq0.hum2};
+    // the (at most four) requested outputs share the pipeline's four output slots
+    float* all_out[5] = {rq0.ff, rq0.temp, rq0.hum, rq0.hum2, rq0.dd};
+    float* h_out[4] = {nullptr, nullptr, nullptr, nullptr};
+    int out_slot[5] = {-1, -1, -1, -1, -1}, n_out = 0;
+    for (int k = 0; k < 5; ++k)
+      if (all_out[k]) {
+        out_slot[k] = n_out;
+        h_out[n_out++] = all_out[k];
+      }
     const mifc::ChunkLaunch launch = [&](int l0, int nl, const float* const* d_in, float* const* d_out, hipStream_t stream) {
       mifc::DerivedParams p = base;
       p.nlev = nl;
@@ -1689,10 +1706,11 @@ int derived_sync(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq
       p.v = slot_v >= 0 ? d_in[slot_v] : nullptr;
       p.t = slot_t >= 0 ? d_in[slot_t] : nullptr;
       p.h = slot_h >= 0 ? d_in[slot_h] : nullptr;
-      p.ff = d_out[0];
-      p.temp = d_out[1];
-      p.hum = d_out[2];
-      p.td = d_out[3];
+      p.ff = out_slot[0] >= 0 ? d_out[out_slot[0]] : nullptr;
+      p.temp = out_slot[1] >= 0 ? d_out[out_slot[1]] : nullptr;
+      p.hum = out_slot[2] >= 0 ? d_out[out_slot[2]] : nullptr;
+      p.td = out_slot[3] >= 0 ? d_out[out_slot[3]] : nullptr;
+      p.dd = out_slot[4] >= 0 ? d_out[out_slot[4]] : nullptr;
       p.alevel = base.alevel + l0;
       p.blevel = base.blevel + l0;
       p.wind_all_defined = base.wind_all_defined + l0;
@@ -1701,13 +1719,14 @@ int derived_sync(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq
       p.cnt_temp = base.cnt_temp + l0;
       p.cnt_hum = base.cnt_hum + l0;
       p.cnt_td = base.cnt_td + l0;
+      p.cnt_dd = base.cnt_dd + l0;
       return mifc::launch_derived_levels(p, stream);
     };
     if (!mifc::hostpipe_run(c->pipe, n, nlev, n_in, h_in, 4, h_out, launch, &c->err))
       return 0;
   } else {
-    rq.u = rq0.ff ? stage_in(c, 0, rq0.u, nb, memkind, &ok) : nullptr;
-    rq.v = rq0.ff ? stage_in(c, 1, rq0.v, nb, memkind, &ok) : nullptr;
+    rq.u = wind ? stage_in(c, 0, rq0.u, nb, memkind, &ok) : nullptr;
+    rq.v = wind ? stage_in(c, 1, rq0.v, nb, memkind, &ok) : nullptr;
     rq.t = thermo ? stage_in(c, 2, rq0.t, nb, memkind, &ok) : nullptr;
     rq.h = humid ? stage_in(c, 3, rq0.h, nb, memkind, &ok) : nullptr;
     rq.ps = thermo ? stage_in(c, 4, rq0.ps, n, memkind, &ok) : nullptr;
@@ -1715,17 +1734,18 @@ int derived_sync(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& rq
     rq.temp = stage_out(c, 6, rq0.temp, nb, memkind, &ok);
     rq.hum = stage_out(c, 7, rq0.hum, nb, memkind, &ok);
     rq.hum2 = stage_out(c, 8, rq0.hum2, nb, memkind, &ok);
+    rq.dd = stage_out(c, 9, rq0.dd, nb, memkind, &ok);
     if (!ok || !ensure_levels(c, (size_t)nlev))
       return 0;
     if (!derived_common(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, undef, c->d_counts))
       return 0;
     if (!fetch_out(c, 5, rq0.ff, nb, memkind) || !fetch_out(c, 6, rq0.temp, nb, memkind) || !fetch_out(c, 7, rq0.hum, nb, memkind) ||
-        !fetch_out(c, 8, rq0.hum2, nb, memkind))
+        !fetch_out(c, 8, rq0.hum2, nb, memkind) || !fetch_out(c, 9, rq0.dd, nb, memkind))
       return 0;
   }
-  MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, 4 * sizeof(u64) * (size_t)nlev, hipMemcpyDeviceToHost, c->stream));
+  MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, 5 * sizeof(u64) * (size_t)nlev, hipMemcpyDeviceToHost, c->stream));
   MIFC_HIP(c, hipStreamSynchronize(c->stream));
-  derived_flags(pinned_counts(c), nlev, n, rq0, fdef_ff, fdef_temp, fdef_hum, fdef_hum2);
+  derived_flags(pinned_counts(c), nlev, n, rq0, fdef_ff, fdef_temp, fdef_hum, fdef_hum2, fdef_dd);
   return 1;
 }
 
@@ -1735,20 +1755,21 @@ extern "C" {
 
 int mifc_hlevel_derived_batch(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* h, const float* ps,
                               const float* alevel, const float* blevel, float* ff, float* temp, const char* temp_unit, int temp_compute, float* hum,
-                              const char* hum_unit, int hum_compute, float* hum2, const char* hum2_unit, int hum2_compute, const int* fdef_wind,
-                              const int* fdef_thermo, int* fdef_ff, int* fdef_temp, int* fdef_hum, int* fdef_hum2, float undef, int memkind)
+                              const char* hum_unit, int hum_compute, float* hum2, const char* hum2_unit, int hum2_compute, float* dd,
+                              const int* fdef_wind, const int* fdef_thermo, int* fdef_ff, int* fdef_temp, int* fdef_hum, int* fdef_hum2, int* fdef_dd,
+                              float undef, int memkind)
 {
   if (!c)
     return 0;
   enter(c);
-  const DerivedRequest rq = {u, v, t, h, ps, alevel, blevel, ff, temp, hum, hum2, temp_unit, hum_unit, hum2_unit, temp_compute, hum_compute, hum2_compute};
-  return derived_sync(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, fdef_ff, fdef_temp, fdef_hum, fdef_hum2, undef, memkind);
+  const DerivedRequest rq = {u, v, t, h, ps, alevel, blevel, ff, temp, hum, hum2, temp_unit, hum_unit, hum2_unit, temp_compute, hum_compute, hum2_compute, dd};
+  return derived_sync(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, fdef_ff, fdef_temp, fdef_hum, fdef_hum2, fdef_dd, undef, memkind);
 }
 
 int mifc_hlevel_derived_batch_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* t, const float* h,
                                       const float* ps, const float* alevel, const float* blevel, float* ff, float* temp, const char* temp_unit,
                                       int temp_compute, float* hum, const char* hum_unit, int hum_compute, float* hum2, const char* hum2_unit,
-                                      int hum2_compute, const int* fdef_wind, const int* fdef_thermo, float undef,
+                                      int hum2_compute, float* dd, const int* fdef_wind, const int* fdef_thermo, float undef,
                                       unsigned long long* n_undefined_dev)
 {
   if (!c || !n_undefined_dev)
@@ -1758,7 +1779,7 @@ int mifc_hlevel_derived_batch_enqueue(mifc_ctx* c, int nx, int ny, int nlev, con
     c->err = "mifc_hlevel_derived_batch: nx*ny must be a multiple of 4 (use the per-field operators otherwise)";
     return 0;
   }
-  const DerivedRequest rq = {u, v, t, h, ps, alevel, blevel, ff, temp, hum, hum2, temp_unit, hum_unit, hum2_unit, temp_compute, hum_compute, hum2_compute};
+  const DerivedRequest rq = {u, v, t, h, ps, alevel, blevel, ff, temp, hum, hum2, temp_unit, hum_unit, hum2_unit, temp_compute, hum_compute, hum2_compute, dd};
   return derived_common(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, undef, n_undefined_dev);
 }
 
@@ -1778,7 +1799,7 @@ int mifc_hlevel_derived_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, co
   }
   if (nlev < 1 || !ensure_levels(c, (size_t)nlev))
     return 0;
-  const DerivedRequest rq = {u, v, t, q, ps, alevel, blevel, ff, theta, rh, nullptr, "", "", "", 3, 1, 0};
+  const DerivedRequest rq = {u, v, t, q, ps, alevel, blevel, ff, theta, rh, nullptr, "", "", "", 3, 1, 0, nullptr};
   if (!derived_common(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, undef, c->d_counts))
     return 0;
   const size_t row = sizeof(u64) * (size_t)nlev;
@@ -1795,8 +1816,8 @@ int mifc_hlevel_derived_levels(mifc_ctx* c, int nx, int ny, int nlev, const floa
   if (!c)
     return 0;
   enter(c);
-  const DerivedRequest rq = {u, v, t, q, ps, alevel, blevel, ff, theta, rh, nullptr, "", "", "", 3, 1, 0};
-  return derived_sync(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, fdef_ff, fdef_theta, fdef_rh, nullptr, undef, memkind);
+  const DerivedRequest rq = {u, v, t, q, ps, alevel, blevel, ff, theta, rh, nullptr, "", "", "", 3, 1, 0, nullptr};
+  return derived_sync(c, nx, ny, nlev, rq, fdef_wind, fdef_thermo, fdef_ff, fdef_theta, fdef_rh, nullptr, nullptr, undef, memkind);
 }
 
 int mifc_vortdiv_slab_enqueue(mifc_ctx* c, int nx, int ny_global, int j0, int ny_local, const float* u_halo, const float* v_halo, const float* xmapr,

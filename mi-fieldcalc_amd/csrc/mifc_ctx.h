@@ -27,7 +27,7 @@ struct mifc_ctx
   size_t slot_bytes[NSLOT] = {0};
   // per-level flags / counters
   unsigned char* d_flags = nullptr; // 2 * cap_lev bytes (wind | thermo, or just one set)
-  u64* d_counts = nullptr;          // 4 * cap_lev
+  u64* d_counts = nullptr;          // 5 * cap_lev
   float* d_ab = nullptr;            // 2 * cap_lev (alevel | blevel; per-level scalars of the batched f1 operators)
   int* d_levels = nullptr;          // cap_lev: level lists of the batched two-stage operators (ALL_DEFINED levels first)
   void* h_pinned = nullptr;         // pinned mirror: counts (3*cap u64) + flags (2*cap) + ab (2*cap float)

@@ -85,6 +85,7 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
   __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
 
   const bool want_ff = FF >= 0 ? (FF != 0) : (P.ff != nullptr);
+  const bool want_dd = P.dd != nullptr; // extension output, wave-uniform at run time in every instantiation
   const int tc = TC >= 0 ? TC : P.temp_compute;
   const int hc = HC >= 0 ? HC : P.hum_code;
   const int dc = DC >= 0 ? DC : P.td_code;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
   const bool d_need_p = want_d && dc != hum_code(HUM_RH_TD, 0);
   const bool read_ps = want_t || h_need_p || d_need_p;
   const bool read_h = want_h || want_d;
-  unsigned int bad_ff = 0, bad_t = 0, bad_h = 0, bad_d = 0;
+  unsigned int bad_ff = 0, bad_t = 0, bad_h = 0, bad_d = 0, bad_dd = 0;
 
   const float* __restrict__ pu = P.u + base;
   const float* __restrict__ pv = P.v + base;
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
   auto load = [&](unsigned q) -> Trip {
     Trip r;
     const unsigned o = q * 4u;
-    r.u = want_ff ? *reinterpret_cast<const v4f*>(pu + o) : zero;
-    r.v = want_ff ? *reinterpret_cast<const v4f*>(pv + o) : zero;
+    r.u = (want_ff || want_dd) ? *reinterpret_cast<const v4f*>(pu + o) : zero;
+    r.v = (want_ff || want_dd) ? *reinterpret_cast<const v4f*>(pv + o) : zero;
     r.t = thermo ? *reinterpret_cast<const v4f*>(pt + o) : zero;
     r.h = read_h ? *reinterpret_cast<const v4f*>(ph + o) : zero;
     r.s = read_ps ? *reinterpret_cast<const v4f*>(ps + o) : zero;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
   float* __restrict__ otemp = P.temp ? P.temp + base : nullptr;
   float* __restrict__ ohum = P.hum ? P.hum + base : nullptr;
   float* __restrict__ otd = P.td ? P.td + base : nullptr;
+  float* __restrict__ odd = P.dd ? P.dd + base : nullptr;
   auto compute = [&](unsigned q, const Trip& in) {
     const unsigned o = q * 4u;
     if (want_ff) { // vectorabs :1831-1837
@@ -156,6 +158,19 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
         }
       }
       st4(off + o, r);
+    }
+    if (want_dd) { // extension: wind direction, flag handling of vectorabs
+      float r[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (wind_all || (is_def(in.u[k], undef) && is_def(in.v[k], undef))) {
+          r[k] = wind_direction(in.u[k], in.v[k]);
+        } else {
+          r[k] = undef;
+          bad_dd += 1;
+        }
+      }
+      st4(odd + o, r);
     }
     if (thermo) {
       float rt[4], rh[4], rd[4];
@@ -247,6 +262,8 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
     wave_count_add(P.cnt_hum + lev, bad_h);
   if (want_d && P.cnt_td)
     wave_count_add(P.cnt_td + lev, bad_d);
+  if (want_dd && CHECK && P.cnt_dd)
+    wave_count_add(P.cnt_dd + lev, bad_dd);
 }
 
 template <bool CHECK>
@@ -267,7 +284,7 @@ void launch_one(const DerivedParams& p, dim3 grid, hipStream_t stream)
     hipLaunchKernelGGL((derived_levels_kernel<CHECK, 0, 3, 1 + HUM_Q_RH, 0>), grid, dim3(256), 0, stream, p);
   else if (tc == 3 && hc == rh && dc == td && !ff)
     hipLaunchKernelGGL((derived_levels_kernel<CHECK, 0, 3, 1 + HUM_Q_RH, 1 + HUM_Q_TD>), grid, dim3(256), 0, stream, p);
-  else if (tc == 0 && hc == 0 && dc == 0)
+  else if (tc == 0 && hc == 0 && dc == 0 && ff)
     hipLaunchKernelGGL((derived_levels_kernel<CHECK, 1, 0, 0, 0>), grid, dim3(256), 0, stream, p);
   else
     hipLaunchKernelGGL((derived_levels_kernel<CHECK, -1, -1, -1, -1>), grid, dim3(256), 0, stream, p);
@@ -308,6 +325,7 @@ hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream)
     p.temp = prm.temp ? prm.temp + off : nullptr;
     p.hum = prm.hum ? prm.hum + off : nullptr;
     p.td = prm.td ? prm.td + off : nullptr;
+    p.dd = prm.dd ? prm.dd + off : nullptr;
     p.alevel = prm.alevel ? prm.alevel + l0 : nullptr;
     p.blevel = prm.blevel ? prm.blevel + l0 : nullptr;
     p.wind_all_defined = prm.wind_all_defined ? prm.wind_all_defined + l0 : nullptr;
@@ -316,6 +334,7 @@ hipError_t launch_derived_levels(const DerivedParams& prm, hipStream_t stream)
     p.cnt_temp = prm.cnt_temp ? prm.cnt_temp + l0 : nullptr;
     p.cnt_hum = prm.cnt_hum ? prm.cnt_hum + l0 : nullptr;
     p.cnt_td = prm.cnt_td ? prm.cnt_td + l0 : nullptr;
+    p.cnt_dd = prm.cnt_dd ? prm.cnt_dd + l0 : nullptr;
     if (prm.every_level_all_defined)
       launch_one<false>(p, dim3(gx, nl), stream);
     else

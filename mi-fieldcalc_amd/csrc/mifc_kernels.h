@@ -75,6 +75,7 @@ struct DerivedParams
   const float *u, *v, *t, *h, *ps; // h: humidity input (q or RH); ps shared by all levels
   const float *alevel, *blevel;    // device float[nlev]
   float *ff, *temp, *hum, *td;     // outputs, any may be null: vectorabs | hleveltemp | hlevelhum | a second hlevelhum variant
+  float* dd;                       // EXTENSION output (may be null): wind direction from u, v, see wind_direction() in mifc_device.h
   int temp_compute;                // hleveltemp compute after the unit remap, 1..5
   int hum_code, td_code;           // 1 + HumKind + 4 * from_theta (0 = none)
   float hum_tdconv, td_tdconv;     // :1181
@@ -82,7 +83,7 @@ struct DerivedParams
   const unsigned char* thermo_all_defined; // device u8[nlev]
   int every_level_all_defined;             // host hint: skip all tests
   float undef;
-  u64 *cnt_ff, *cnt_temp, *cnt_hum, *cnt_td; // device u64[nlev] each (level 0 of this launch first)
+  u64 *cnt_ff, *cnt_temp, *cnt_hum, *cnt_td, *cnt_dd; // device u64[nlev] each (level 0 of this launch first)
   // small batches (nlev <= 8, e.g. the single level of BASELINE.json config 2)
   // carry the per-level scalars in the kernel arguments: no upload before the launch
   int n_inline; // != 0: use the arrays below instead of the device arrays above

@@ -303,3 +303,54 @@ def test_cxx_library_exports_the_reference_symbols(built):
     internal = {s for s in ref if "compute_num_threads" in s or "bad_hlevel" in s}
     assert len(ref) > 70
     assert not (ref - internal - mine), sorted(ref - internal - mine)
+
+
+def _header_prototypes():
+    """name -> number of parameters, for every function declared in include/mifc.h."""
+    text = open(os.path.join(ROOT, "include", "mifc.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(mifc_[a-zA-Z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    return protos
+
+
+def test_python_binding_mirrors_the_header():
+    """The ctypes table (mi-fieldcalc_amd/_capi.py) is hand-written: every prototype of include/mifc.h must be in
+    it with the same number of parameters -- a drifted signature would pass garbage across the C ABI."""
+    import mi_fieldcalc_amd._capi as capi
+
+    protos = _header_prototypes()
+    assert len(protos) > 90
+    missing = sorted(set(protos) - set(capi.SIGNATURES))
+    assert not missing, missing
+    for name, (res, args) in capi.SIGNATURES.items():
+        assert name in protos, name + " is bound but not declared in include/mifc.h"
+        assert len(args) == protos[name], (name, len(args), protos[name])
+
+
+def test_measurement_knobs_exist_in_the_measurement_build_only(built):
+    """knobs that give wrong results by design (loads / stores / halo rows switched off) must not be
+    reachable in the library callers link.  They are compiled into libmifc_measure.so (tools/ only)."""
+    product = open(LIB, "rb").read()
+    measure_path = os.path.join(ROOT, "mi-fieldcalc_amd", "libmifc_measure.so")
+    assert os.path.exists(measure_path)
+    measure = open(measure_path, "rb").read()
+    for key in (b"PADROWS", b"MIFC_MEASUREMENT_KNOBS"):
+        assert key not in product, key
+    assert b"PADROWS" in measure
+    pkg = os.path.join(ROOT, "mi-fieldcalc_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            assert "libmifc_measure" not in open(os.path.join(pkg, f)).read(), f
+
+
+def test_environment_is_read_in_one_place_only():
+    """No launch path calls getenv: the MIFC_* variables are read into a snapshot by mifc_create / mifc_reload_env
+    (csrc/mifc_env.hip); MIFC_DEVICE belongs to the C++ API's per-thread context (src/FieldCalculations.cc)."""
+    csrc = os.path.join(ROOT, "mi-fieldcalc_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")) and f != "mifc_env.hip":
+            code = re.sub(r"//.*", "", open(os.path.join(csrc, f)).read())
+            assert "getenv" not in code, f

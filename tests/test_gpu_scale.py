@@ -326,6 +326,14 @@ def test_derived_batch_every_variant(gpu_ctx, oracle, nlev):
         _check_derived_batch(gpu_ctx, oracle, u, v, t, hh, ps, a, b, fw, ft, temp, hum, hum2, ff, device=True)
     # a bad hybrid level -> false, like the reference (:298)
     assert gpu_ctx.hlevel_derived_batch(u, v, t, q, ps, -a, b, temp=("", 3), fdef_wind=fw, fdef_thermo=ft) is None
+    # the wind direction (extension) as a fifth output: what mifc_winddir gives per level, flags included
+    res, flags = gpu_ctx.hlevel_derived_batch(u, v, t, q, ps, a, b, temp=("", 3), hum=("", 1), hum2=("", 9), dd=True, fdef_wind=fw, fdef_thermo=ft)
+    only_dd, flags2 = gpu_ctx.hlevel_derived_batch(u, v, None, None, None, None, None, ff=False, dd=True, fdef_wind=fw)
+    for l in range(nlev):
+        e, f = gpu_ctx.winddir(u[l], v[l], fdefined=int(fw[l]))
+        assert _bits_equal(res["dd"][l], e) and _bits_equal(only_dd["dd"][l], e) and flags["dd"][l] == f == flags2["dd"][l]
+        ok, e, f = oracle.call("vectorabs", nx, ny, u[l], v[l], fdefined=int(fw[l]))
+        assert _bits_equal(res["ff"][l], e) and flags["ff"][l] == f
 
 
 @pytest.mark.parametrize("mode", ["all", "some"])

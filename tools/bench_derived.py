@@ -31,8 +31,8 @@ def main():
     for s in range(2):
         u, v = synth.device_wind(NX, NY, NLEV, 100 + s, dev)
         t, q, ps = synth.device_thermo(NX, NY, NLEV, 200 + s, dev)
-        sets.append(dict(u=u, v=v, t=t, q=q, ps=ps, out={k: torch.empty_like(u) for k in ("ff", "temp", "hum", "hum2")}))
-    cnt = torch.zeros(4 * NLEV, dtype=torch.int64, device=dev)
+        sets.append(dict(u=u, v=v, t=t, q=q, ps=ps, out={k: torch.empty_like(u) for k in ("ff", "temp", "hum", "hum2", "dd")}))
+    cnt = torch.zeros(5 * NLEV, dtype=torch.int64, device=dev)
     n = NX * NY * NLEV
     print("%dx%dx%d, kernel ms by HIP events (median of 9), two rotating buffer sets" % (NX, NY, NLEV))
     print("%-34s %-14s %8s %9s %7s" % ("outputs", "flags / blocks", "ms", "GB/s", "frac"))
@@ -45,7 +45,8 @@ def main():
         if os.environ.get("DERIVED_ONLY_TRIO"):
             pass
         for name, kw, bytes_per_cell in (("ff + RH + theta", dict(temp=("", 3), hum=("", 1)), 28), ("ff + RH + theta + Td", dict(temp=("", 3), hum=("", 1), hum2=("", 9)), 32),
-                                         ("RH + theta (no wind)", dict(temp=("", 3), hum=("", 1), ff=False), 16)):
+                                         ("RH + theta (no wind)", dict(temp=("", 3), hum=("", 1), ff=False), 16),
+                                         ("ff + dd + RH + theta + Td", dict(temp=("", 3), hum=("", 1), hum2=("", 9), dd=True), 36)):
             for flag in (fc.ALL_DEFINED, fc.SOME_DEFINED):
                 flags = np.full(NLEV, flag, np.int32)
                 ms = []
