@@ -82,7 +82,7 @@ template <bool CHECK, int FF, int TC, int HC, int DC, bool PIPE = true>
 __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams P)
 {
   __shared__ float s_ewt[MIFC_EWT_LDS];
-  __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
+  __shared__ double s_pow[MIFC_KAPPA_LDS];
 
   const bool want_ff = FF >= 0 ? (FF != 0) : (P.ff != nullptr);
   const bool want_dd = P.dd != nullptr; // extension output, wave-uniform at run time in every instantiation
@@ -95,13 +95,7 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
   // x^kappa for every temperature variant and the humidity variants that start from theta
   const bool need_ewt = want_h || want_d || tc >= 4;
   const bool need_pow = want_t || hc >= 5 || dc >= 5;
-  if (need_ewt)
-    ewt_table_init(s_ewt);
-  PowTables PT;
-  PT.logt = s_pow;
-  PT.expt = s_pow + 2 * MIFC_POW_LOG_N;
-  if (need_pow)
-    PT = pow_tables_init(s_pow);
+  PowTables PT = {nullptr, nullptr, s_pow, s_pow + 2 * MIFC_KAPPA_N};
 
   const int lev = blockIdx.y;
   const size_t base = (size_t)lev * (size_t)P.n;
@@ -231,11 +225,18 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
 
   // two trips per iteration: the loads of the next trip are in flight while this one is computed
   unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  // the loads of the first trip go out before the lookup tables (4.9 KiB) are staged in LDS
+  Trip cur = load(q < n4 ? q : 0u);
+  if (need_ewt)
+    ewt_table_init(s_ewt);
+  if (need_pow)
+    PT = kappa_tables_init(s_pow);
   if (!PIPE) {
-    for (; q < n4; q += stride)
+    if (q < n4)
+      compute(q, cur);
+    for (q += stride; q < n4; q += stride)
       compute(q, load(q));
   } else if (q < n4) {
-    Trip cur = load(q);
     for (;;) {
       const unsigned q1 = q + stride;
       const bool more1 = q1 < n4;

@@ -129,21 +129,21 @@ __device__ __forceinline__ float clamp_rh(float rh)
 // nearly correctly rounded float (1 ulp off in 0.07 % of the arguments).  The
 // device's float powf is several ulp off, and the saturation-pressure table
 // amplifies a temperature error (up to ~0.3 per kelvin at its cold end), so
-// the power is taken in double here, with a purpose-built table-driven
-// x^kappa (tables generated and verified by tools/gen_pow_tables.py):
-//   x = m * 2^e, m in [sqrt(1/2), sqrt(2))           (integer ops on the float)
-//   i = top 4 mantissa-offset bits -> 16 sub-intervals with centre c_i
-//   r = m/c_i - 1, |r| <= 1/32;  log2 m = log2 c_i + r/ln2 (1 - r/2 + ... - r^5/6)
-//   t = kappa (e + log2 m);  k = rint(32 t);  g = (t - k/32) ln 2, |g| <= 0.011
-//   x^kappa = 2^(k>>5) * 2^((k&31)/32) * (1 + g + g^2/2 + g^3/6 + g^4/24)
-// ~22 fp64-pipe operations + two LDS reads; the float result equals the
-// correctly rounded power in all but 12 of 4.5e6 sampled arguments (1 ulp).
-// Agreement with glibc is "identical in 99.9 % of the cells, 1 ulp otherwise";
-// the parity bound for the operators that use it is 1e-5 relative
+// the power is taken in double here.  Round 2: DIRECT tables for this one
+// exponent (mifc_kappa_tables.h, generated and verified by tools/gen_kappa_tables.py):
+//   x = 2^e * m, m in [1, 2);  i = top 8 mantissa bits -> 256 intervals, centre c_i
+//   r = m * (1/c_i) - 1, |r| <= 2^-9
+//   x^kappa = 2^(kappa e) * c_i^kappa * (1 + k1 r + k2 r^2 + k3 r^3)     (truncation <= 6e-13 relative)
+// 8 fp64-pipe operations + one 16-byte and one 8-byte LDS read, instead of the 26
+// of the log2 / exp2 route below (kept for the generic powers of the catalogue);
+// the float result equals the correctly rounded power in all but 2 of 4.5e6 sampled
+// arguments (1 ulp).  Agreement with glibc is "identical in 99.9 % of the cells,
+// 1 ulp otherwise"; the parity bound for the operators that use it is 1e-5 relative
 // (BASELINE.json), not bit-exact.  The fused multiply-adds are explicit here
-// (accuracy, not parity, matters).  Special values behave like powf with a
-// positive non-integer exponent: x<0 -> NaN, 0 -> 0, inf -> inf, NaN -> NaN
-// (generic slow path, out of line).
+// (accuracy, not parity, matters).  Arguments outside [2^-32, 2^32) -- no pressure
+// is -- and special values behave like powf with a positive non-integer exponent:
+// x<0 -> NaN, 0 -> 0, inf -> inf, NaN -> NaN (generic slow path, out of line).
+#include "mifc_kappa_tables.h"
 #define MIFC_POW_LOG_N 16
 #define MIFC_POW_EXP_N 32
 __device__ const double mifc_pow_log_tab[MIFC_POW_LOG_N][2] = { // {1/c_i, log2 c_i}
@@ -177,9 +177,12 @@ __device__ const double mifc_pow_exp_tab[MIFC_POW_EXP_N] = { // 2^(j/32)
 
 struct PowTables
 {
-  const double* logt; // LDS, [16][2]
+  const double* logt; // LDS, [16][2]: generic log2 (log_float / exp_float / pow_float)
   const double* expt; // LDS, [32]
+  const double* kit;  // LDS, [256][2] = {1/c_i, c_i^kappa}: pow_kappa
+  const double* ket;  // LDS, [64] = 2^(kappa e)
 };
+#define MIFC_KAPPA_LDS (2 * MIFC_KAPPA_N + MIFC_KAPPA_NE) // doubles
 
 // stages both tables in LDS (512 B); call once per workgroup before the first use
 __device__ __forceinline__ PowTables pow_tables_init(double* lds_tab /* 64 doubles */)
@@ -192,6 +195,24 @@ __device__ __forceinline__ PowTables pow_tables_init(double* lds_tab /* 64 doubl
   PowTables t;
   t.logt = lds_tab;
   t.expt = lds_tab + 2 * MIFC_POW_LOG_N;
+  t.kit = nullptr;
+  t.ket = nullptr;
+  return t;
+}
+
+// stages the x^kappa tables in LDS (4.6 KiB); call once per workgroup before the first pow_kappa
+__device__ __forceinline__ PowTables kappa_tables_init(double* lds_tab /* MIFC_KAPPA_LDS doubles */)
+{
+  for (int k = threadIdx.x; k < 2 * MIFC_KAPPA_N; k += blockDim.x)
+    lds_tab[k] = (&mifc_kappa_it[0][0])[k];
+  for (int k = threadIdx.x; k < MIFC_KAPPA_NE; k += blockDim.x)
+    lds_tab[2 * MIFC_KAPPA_N + k] = mifc_kappa_et[k];
+  __syncthreads();
+  PowTables t;
+  t.logt = nullptr;
+  t.expt = nullptr;
+  t.kit = lds_tab;
+  t.ket = lds_tab + 2 * MIFC_KAPPA_N;
   return t;
 }
 
@@ -248,9 +269,18 @@ __device__ __forceinline__ double exp2_tab(const PowTables& T, double t)
 
 __device__ __forceinline__ float pow_kappa(const PowTables& T, float x)
 {
-  if (!(x >= 1.0e-30f && x <= 1.0e30f))
+  if (!(x >= 2.3283064365386963e-10f /* 2^-32 */ && x < 4294967296.0f /* 2^32 */))
     return pow_kappa_slow(x);
-  return (float)exp2_tab(T, (double)MIFC_K_KAPPA * log2_tab(T, x));
+  const int ix = __float_as_int(x);
+  const int e = (ix >> 23) - 127; // x is positive and normal here
+  const int i = (ix >> 15) & 0xff;
+  const double m = (double)__int_as_float((ix & 0x007fffff) | 0x3f800000);
+  const double r = fma(m, T.kit[2 * i], -1.0);
+  double p = MIFC_KAPPA_K3;
+  p = fma(p, r, MIFC_KAPPA_K2);
+  p = fma(p, r, MIFC_KAPPA_K1);
+  p = fma(p, r, 1.0);
+  return (float)(T.ket[e - MIFC_KAPPA_EMIN] * T.kit[2 * i + 1] * p);
 }
 
 // ---- the float libm functions of the catalogue (logf, log10f, expf, powf and the double exp / pow the

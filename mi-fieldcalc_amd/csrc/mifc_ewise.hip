@@ -171,17 +171,16 @@ template <int OP, bool VEC4>
 __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
 {
   __shared__ float s_ewt[MIFC_EWT_LDS];
-  __shared__ double s_pow[2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N];
+  constexpr bool USES_POW = (OP == EW_TEMP || OP == EW_TEMP_PLAIN || OP == EW_HUM || OP == EW_HUM_DIRECT);
+  __shared__ double s_pow[USES_POW ? MIFC_KAPPA_LDS : 1];
   // the lookup tables cost a few hundred cycles per workgroup: staged only
   // for the operator variants that read them (wave-uniform conditions)
   constexpr bool TABLE_FREE = (OP == EW_TEMP_SCALAR || OP == EW_VECTORABS || OP == EW_MOMENTUM_X || OP == EW_MOMENTUM_Y);
   if (!TABLE_FREE && ewise_needs_ewt(P))
     ewt_table_init(s_ewt);
-  PowTables PT;
-  PT.logt = s_pow;
-  PT.expt = s_pow + 2 * MIFC_POW_LOG_N;
-  if (!TABLE_FREE && ewise_needs_pow(P))
-    PT = pow_tables_init(s_pow);
+  PowTables PT = {nullptr, nullptr, s_pow, s_pow};
+  if (USES_POW && ewise_needs_pow(P))
+    PT = kappa_tables_init(s_pow);
 
   const bool use1 = P.in1 != nullptr;
   const bool use2 = P.in2 != nullptr;

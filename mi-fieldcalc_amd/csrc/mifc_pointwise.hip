@@ -31,37 +31,37 @@ struct PwTraits;
   {                                      \
     static const int nin = NIN;          \
     static const bool ewt = EWT;         \
-    static const bool pow = POW;         \
+    static const int pow = POW;          \
   }
-PW_TRAITS(PW_PLEVELTHE, 2, true, false);
-PW_TRAITS(PW_XLEVELTHE, 3, false, true);
-PW_TRAITS(PW_PDUCT, 2, true, false);
-PW_TRAITS(PW_XDUCT, 3, true, true);
-PW_TRAITS(PW_HPRESSURE, 1, false, false);
-PW_TRAITS(PW_DZ2TMEAN, 2, false, false);
-PW_TRAITS(PW_KINDEX, 5, true, false);
-PW_TRAITS(PW_DUCTINDEX, 2, true, false);
-PW_TRAITS(PW_SHOWALTER, 3, true, false);
-PW_TRAITS(PW_BOYDEN, 3, false, false);
-PW_TRAITS(PW_SWEAT, 8, false, false);
-PW_TRAITS(PW_SOUNDSPEED, 2, false, false);
-PW_TRAITS(PW_ADDCONST, 1, false, false);
-PW_TRAITS(PW_ABSHUM, 2, false, true);
-PW_TRAITS(PW_WINDCOOLING, 3, false, true);
-PW_TRAITS(PW_UNDERCOOLED, 3, false, false);
-PW_TRAITS(PW_FLIGHTLEVEL, 1, false, false);
-PW_TRAITS(PW_SNOWCM, 3, false, true);
-PW_TRAITS(PW_CLASSES, 1, false, false);
-PW_TRAITS(PW_MINMAX_FIELDS, 2, false, false);
-PW_TRAITS(PW_MINMAX_CONST, 1, false, false);
-PW_TRAITS(PW_MATH, 1, false, true);
-PW_TRAITS(PW_REPLACE, 1, false, false);
-PW_TRAITS(PW_FILL, 0, false, false);
-PW_TRAITS(PW_FIELD_OP_FIELD, 2, false, false);
-PW_TRAITS(PW_FIELD_OP_CONST, 1, false, false);
-PW_TRAITS(PW_CONST_OP_FIELD, 1, false, false);
-PW_TRAITS(PW_VESSEL_ICING, 6, false, false);
-PW_TRAITS(PW_WINDDIR, 2, false, false);
+PW_TRAITS(PW_PLEVELTHE, 2, true, 0);
+PW_TRAITS(PW_XLEVELTHE, 3, false, 2);
+PW_TRAITS(PW_PDUCT, 2, true, 0);
+PW_TRAITS(PW_XDUCT, 3, true, 2);
+PW_TRAITS(PW_HPRESSURE, 1, false, 0);
+PW_TRAITS(PW_DZ2TMEAN, 2, false, 0);
+PW_TRAITS(PW_KINDEX, 5, true, 0);
+PW_TRAITS(PW_DUCTINDEX, 2, true, 0);
+PW_TRAITS(PW_SHOWALTER, 3, true, 0);
+PW_TRAITS(PW_BOYDEN, 3, false, 0);
+PW_TRAITS(PW_SWEAT, 8, false, 0);
+PW_TRAITS(PW_SOUNDSPEED, 2, false, 0);
+PW_TRAITS(PW_ADDCONST, 1, false, 0);
+PW_TRAITS(PW_ABSHUM, 2, false, 1);
+PW_TRAITS(PW_WINDCOOLING, 3, false, 1);
+PW_TRAITS(PW_UNDERCOOLED, 3, false, 0);
+PW_TRAITS(PW_FLIGHTLEVEL, 1, false, 0);
+PW_TRAITS(PW_SNOWCM, 3, false, 1);
+PW_TRAITS(PW_CLASSES, 1, false, 0);
+PW_TRAITS(PW_MINMAX_FIELDS, 2, false, 0);
+PW_TRAITS(PW_MINMAX_CONST, 1, false, 0);
+PW_TRAITS(PW_MATH, 1, false, 1);
+PW_TRAITS(PW_REPLACE, 1, false, 0);
+PW_TRAITS(PW_FILL, 0, false, 0);
+PW_TRAITS(PW_FIELD_OP_FIELD, 2, false, 0);
+PW_TRAITS(PW_FIELD_OP_CONST, 1, false, 0);
+PW_TRAITS(PW_CONST_OP_FIELD, 1, false, 0);
+PW_TRAITS(PW_VESSEL_ICING, 6, false, 0);
+PW_TRAITS(PW_WINDDIR, 2, false, 0);
 #undef PW_TRAITS
 
 // MetConstants.h:46 (rcp, cplr, exl), :53 (ms2knots), :88-90 (flight-level tables)
@@ -465,10 +465,9 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
   constexpr int NIN = PwTraits<OP>::nin;
   constexpr int NV = NIN > 0 ? NIN : 1;
   __shared__ float s_ewt[PwTraits<OP>::ewt ? MIFC_EWT_LDS : 1];
-  __shared__ double s_pow[PwTraits<OP>::pow ? (2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N) : 1];
-  PowTables PT;
-  PT.logt = s_pow;
-  PT.expt = s_pow;
+  // x^kappa tables (theta-e, ducting from theta) or the generic log2 / exp2 tables (the libm-class functions)
+  __shared__ double s_pow[PwTraits<OP>::pow == 2 ? MIFC_KAPPA_LDS : (PwTraits<OP>::pow == 1 ? (2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N) : 1)];
+  PowTables PT = {s_pow, s_pow, s_pow, s_pow};
 
   const bool all = P.all_defined != 0;
   const float undef = P.undef;
@@ -491,8 +490,10 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
       fetch(q);
     if (PwTraits<OP>::ewt)
       ewt_table_init(s_ewt);
-    if (PwTraits<OP>::pow)
+    if (PwTraits<OP>::pow == 1)
       PT = pow_tables_init(s_pow);
+    if (PwTraits<OP>::pow == 2)
+      PT = kappa_tables_init(s_pow);
     while (q < n4) {
       float o[4] = {old.x, old.y, old.z, old.w};
 #pragma unroll
@@ -524,8 +525,10 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
   } else {
     if (PwTraits<OP>::ewt)
       ewt_table_init(s_ewt);
-    if (PwTraits<OP>::pow)
+    if (PwTraits<OP>::pow == 1)
       PT = pow_tables_init(s_pow);
+    if (PwTraits<OP>::pow == 2)
+      PT = kappa_tables_init(s_pow);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += gridDim.x * blockDim.x) {
       float x[NV];
       bool def = true;
