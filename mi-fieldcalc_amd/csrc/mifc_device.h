@@ -506,6 +506,8 @@ __device__ __forceinline__ float wind_direction(float u, float v)
 // ---- undefined-cell counting: one atomic per wave, none when nothing to add
 __device__ __forceinline__ void wave_count_add(u64* counter, unsigned int my_count)
 {
+  if (__builtin_amdgcn_ballot_w64(my_count != 0) == 0) // nothing to count in this wave (the usual case): no shuffles, no atomic
+    return;
   // wave64 butterfly sum
   unsigned int s = my_count;
 #pragma unroll

@@ -49,6 +49,7 @@ void env_reload()
   e.host_chunk_mib = positive_int("MIFC_HOST_CHUNK_MIB");
   e.derived_blocks = positive_int("MIFC_DERIVED_BLOCKS");
   e.derived_pipe = not_zero("MIFC_DERIVED_PIPE") ? 1 : 0;
+  e.levelwalk = not_zero("MIFC_VORTDIV_LEVELWALK");
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     e.has_vortdiv_tune = true;
     std::strncpy(e.vortdiv_tune, s, sizeof e.vortdiv_tune - 1);

@@ -48,6 +48,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace mifc {
 
@@ -744,9 +745,252 @@ __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsP
     wave_count_add(P.n_undefined + lev, bad);
 }
 
+
+// ---------------------------------------------------------------------------
+// Level-walking form (tuning K=3): a workgroup is NW waves = NW consecutive rows x 256 columns of a
+// tile -- and it STAYS on its tile and walks through the levels of the batch.
+//   * xmapr / ymapr of the tile do not depend on the level: every wave loads its row of them ONCE,
+//     into registers, for all its levels (map factors once per level chunk);
+//   * the workgroups of the launch advance level by level together, so at any time the chip works
+//     inside a window of a few levels of each array -- the access pattern of a streaming copy that
+//     happens to be cut into tiles -- instead of the 16+ levels a row-walking launch has open at once;
+//   * per level a wave loads its row of u and v (the loads of level l+PF are issued before level l is
+//     computed; static register sets, the loop is unrolled over them so that no in-flight register
+//     is ever moved), parks it in one of two LDS buffers, ONE barrier (LDS counter only: prefetches
+//     and stores stay in flight across it), takes the rows above and below from LDS, x-neighbours
+//     from the adjacent lanes (DPP), stores 2 x 1 KiB;
+//   * the first and the last wave also load the halo row above / below the tile: (NW+2)/NW requests at
+//     L1, but the workgroup above / below reads the same rows of the same level at about the same
+//     time on the same XCD (consecutive units -> one XCD): L2 hits.
+//   * HALO = true instead gives the two halo rows waves of their own (the first and the last wave of the
+//     workgroup only load): NW - 2 computed rows per tile, but no extra row in anybody's registers.
+// Registers: with halo waves and one level of prefetch the kernel fits 64 VGPRs, i.e. two 16-wave (or four
+// 8-wave) workgroups per CU -- asked for through the second launch bound (waves per SIMD).
+template <bool CHECK, bool WANT_V, bool WANT_D, bool NT, int NW, int PF, bool HALO>
+__global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1) void vortdiv_levelwalk_kernel(const RowsParams P)
+{
+  constexpr int TR = HALO ? NW - 2 : NW; // rows of the tile
+  __shared__ v4f su[2][TR + 2][64];
+  __shared__ v4f sv[2][TR + 2][64];
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int bid = blockIdx.x;
+  const int seq = P.xcd_remap ? ((bid & 7) * P.per_xcd + (bid >> 3)) : bid;
+  if (seq >= P.n_logical)
+    return;
+  // unit = (level chunk, row block, column segment): column segment fastest, level chunk slowest
+  const int ntiles = P.uB * P.uW;
+  const int lchunk = seq / ntiles;
+  const int tile = seq - lchunk * ntiles;
+  const int rblock = tile / P.uW;
+  const int wc = tile - rblock * P.uW;
+  const int lev0 = lchunk * P.lgroup;
+  const int lev1 = (lev0 + P.lgroup < P.nlev) ? lev0 + P.lgroup : P.nlev;
+
+  const int nx = P.nx;
+  const int first = P.lo + rblock * TR; // first row of the tile (always computed)
+  // LDS slot s holds tile row s - 1 (slot 0: the row above the tile, slot TR + 1: the row below)
+  const int slot = HALO ? wave : wave + 1;
+  const int jl_raw = first + slot - 1;
+  const bool computes = (!HALO || (wave >= 1 && wave <= TR)) && jl_raw < P.hi;
+  const int jl = jl_raw < P.hi ? jl_raw : P.hi; // rows past the computed range: only loaded (row `hi` always exists), for the wave above
+  const int j = P.j0 + jl;
+  // without halo waves the first wave also brings the row above the tile, the last wave the row below
+  const bool has_extra = !HALO && ((wave == 0) || (wave == NW - 1));
+  const int extra_row = (wave == 0) ? first - 1 : ((first + NW < P.hi) ? first + NW : P.hi);
+  const int extra_slot = (wave == 0) ? 0 : NW + 1;
+  const int col = wc * 256 + lane * 4;
+  const bool act = col < nx;
+  const int col_c = act ? col : nx - 4;
+  int east_col = wc * 256 + 256;
+  if (east_col > nx)
+    east_col = nx;
+  const int edge_col = (lane == 63) ? east_col : (wc * 256 - 1);
+  const float undef = P.undef;
+  // offsets inside one level fit 32 bits (the launcher checks): half the registers of 64-bit ones, and they live through the whole walk
+  const int base = jl * nx;
+  const int o = base + col_c;
+  const int ox = extra_row * nx + col_c;
+  long e64 = (long)base + edge_col;
+  e64 = e64 < P.idx_lo ? P.idx_lo : (e64 > P.idx_hi ? P.idx_hi : e64);
+  const int e = (int)e64;
+  const bool top = (j == 1) && (P.j0 == 0);
+  const bool bottom = (j == P.nyg - 2) && (P.j0 + P.ny_local == P.nyg);
+  const bool last_in_seg = col + 4 >= east_col;
+  const int oo = base + col;
+
+  // the tile's map factors: once, for every level of the chunk
+  v4f xm4 = {0.f, 0.f, 0.f, 0.f}, ym4 = xm4;
+  if (computes) {
+    xm4 = load4(P.xm + o);
+    ym4 = load4(P.ym + o);
+  }
+  struct LevRegsX
+  {
+    v4f u, v, xu, xv;
+    float eu, ev;
+  };
+  struct LevRegsH
+  {
+    v4f u, v;
+    float eu, ev;
+  };
+  typedef typename std::conditional<HALO, LevRegsH, LevRegsX>::type LevRegs;
+  auto load_level = [&](int lev) -> LevRegs {
+    const int l = lev < lev1 ? lev : lev1 - 1; // past the chunk: a valid address, never used
+    const float* __restrict__ u = P.u + (size_t)l * P.in_stride;
+    const float* __restrict__ v = P.v + (size_t)l * P.in_stride;
+    LevRegs r;
+#ifdef MIFC_MEASUREMENT_BUILD
+    if (P.exp_noload) { // write side alone
+      const float f = (float)(lev + lane);
+      const v4f z = {f, f + 1.f, f * 2.f, f + 3.f};
+      r.u = z;
+      r.v = z;
+      if constexpr (!HALO) {
+        r.xu = z;
+        r.xv = z;
+      }
+      r.eu = 0.f;
+      r.ev = 0.f;
+      return r;
+    }
+#endif
+    r.u = load4(u + o);
+    r.v = load4(v + o);
+    if constexpr (!HALO) {
+      r.xu = r.u;
+      r.xv = r.v;
+      if (has_extra) {
+        r.xu = load4(u + ox);
+        r.xv = load4(v + ox);
+      }
+    }
+    r.eu = u[e];
+    r.ev = v[e];
+    return r;
+  };
+  LevRegs R[PF + 1];
+#pragma unroll
+  for (int k = 0; k < PF; ++k)
+    R[k] = load_level(lev0 + k);
+
+  for (int lb = lev0; lb < lev1; lb += PF + 1) {
+#pragma unroll
+    for (int s = 0; s <= PF; ++s) {
+      const int lev = lb + s;
+      if (lev >= lev1)
+        goto chunk_done;
+      R[(s + PF) % (PF + 1)] = load_level(lev + PF); // in flight while this level and the next PF-1 are computed
+      const LevRegs& C = R[s];
+      const int buf = (lev - lev0) & 1;
+      su[buf][slot][lane] = C.u;
+      sv[buf][slot][lane] = C.v;
+      if constexpr (!HALO) {
+        if (has_extra) {
+          su[buf][extra_slot][lane] = C.xu;
+          sv[buf][extra_slot][lane] = C.xv;
+        }
+      }
+      // LDS rows of this level visible to the workgroup; only the LDS counter is waited for -- the prefetches
+      // above and the stores of the previous levels stay in flight across the barrier.  Two buffers: a wave
+      // can only overwrite buffer b again after the barrier of the level in between, which every wave reaches
+      // with its reads of b consumed.
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (computes) {
+        const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
+        // two passes, vorticity then divergence, each taking its rows from LDS when it needs them and storing at
+        // once: fewer live registers than one fused pass (the variant with tests spilled otherwise)
+        const v4f uc = C.u, vc = C.v;
+        const float east_u = readlane_f(C.eu, 63), east_v = readlane_f(C.ev, 63);
+        float uW = dpp_from_lower_lane(C.eu, uc.w), vW = dpp_from_lower_lane(C.ev, vc.w);
+        float uE = dpp_from_upper_lane(C.eu, uc.x), vE = dpp_from_upper_lane(C.ev, vc.x);
+        if (last_in_seg) {
+          uE = east_u;
+          vE = east_v;
+        }
+        bool ok[4] = {true, true, true, true};
+        unsigned int bad = 0;
+        {
+          const v4f un = su[buf][slot + 1][lane], us = su[buf][slot - 1][lane];
+          const float vcx[6] = {vW, vc.x, vc.y, vc.z, vc.w, vE};
+          float zv[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float vw = vcx[k], ve = vcx[k + 2];
+            if (CHECK) // both operators test these four values (:1861, :1927)
+              ok[k] = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef));
+            if (WANT_V)
+              zv[k] = ok[k] ? f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]) : undef;
+            if (CHECK && !ok[k] && act)
+              bad += 1;
+          }
+          if (WANT_V) {
+            if (col == 0) // fillEdges, column part (:65-68)
+              zv[0] = zv[1];
+            if (col + 4 == nx)
+              zv[3] = zv[2];
+#ifdef MIFC_MEASUREMENT_BUILD
+            if (act && !(P.exp_nostore && zv[0] != 12345.678f)) {
+#else
+            if (act) {
+#endif
+              float* rv = P.rv + (size_t)lev * P.out_stride;
+              v4f z4;
+              z4.x = zv[0];
+              z4.y = zv[1];
+              z4.z = zv[2];
+              z4.w = zv[3];
+              store4<NT>(rv + oo, z4);
+              if (top) // fillEdges, row part (:70-73)
+                store4<NT>(rv + oo - nx, z4);
+              if (bottom)
+                store4<NT>(rv + oo + nx, z4);
+            }
+          }
+        }
+        if (WANT_D) {
+          if (WANT_V)
+            __builtin_amdgcn_sched_barrier(0);
+          const v4f vn = sv[buf][slot + 1][lane], vs = sv[buf][slot - 1][lane];
+          const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
+          float zd[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            zd[k] = ok[k] ? f_diverg(xm4[k], ym4[k], ucx[k + 2] - ucx[k], vn[k] - vs[k]) : undef;
+          if (col == 0)
+            zd[0] = zd[1];
+          if (col + 4 == nx)
+            zd[3] = zd[2];
+#ifdef MIFC_MEASUREMENT_BUILD
+          if (act && !(P.exp_nostore && zd[0] != 12345.678f)) {
+#else
+          if (act) {
+#endif
+            float* dv = P.dv + (size_t)lev * P.out_stride;
+            v4f d4;
+            d4.x = zd[0];
+            d4.y = zd[1];
+            d4.z = zd[2];
+            d4.w = zd[3];
+            store4<NT>(dv + oo, d4);
+            if (top)
+              store4<NT>(dv + oo - nx, d4);
+            if (bottom)
+              store4<NT>(dv + oo + nx, d4);
+          }
+        }
+        if (CHECK && P.n_undefined && !all)
+          wave_count_add(P.n_undefined + lev, bad);
+      }
+    }
+  }
+chunk_done:;
+}
+
 struct Tuning
 {
-  int K;     // 0: row-walking kernel (default), 1: one-shot kernel, 2: one-shot tiles with the row reuse in LDS
+  int K;     // 0: row-walking kernel (default), 1: one-shot kernel, 2: one-shot tiles with the row reuse in LDS, 3: level-walking tiles
   int R;     // rows per band
   int D;     // rows kept in flight beyond the 3-row window (0 or 1)
   int NT;    // nontemporal stores
@@ -879,6 +1123,10 @@ void launch_outputs(const RowsParams& rp, const Tuning& t, int grid, hipStream_t
     launch_d<CHECK, false, true, false>(rp, t, grid, stream);
 }
 
+// when the level-walking form takes over from the row-walking one (measured: profiles/r02/experiments/levelwalk_threshold.txt)
+constexpr int kLevelWalkMinLevels = 3;
+constexpr long kLevelWalkMinUnits = 768;
+
 inline bool aligned16(const void* p)
 {
   return (reinterpret_cast<size_t>(p) & 15u) == 0;
@@ -948,6 +1196,22 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       // that way, 66 % one-shot, 69 % as one-shot tiles with the row reuse in LDS
       // (profiles/r01/other_configs.jsonl, cold numbers).
       t.K = (small || prm.op == ST_JACOBIAN) ? 1 : 2;
+    }
+    else if (prm.op != ST_JACOBIAN && prm.op != ST_ABSVORT && prm.nlev >= kLevelWalkMinLevels && env().levelwalk) {
+      // Deep batches: tiles that stay put and walk the levels (map factors once per chunk of levels, a narrow
+      // window of each array open at any time).  12-wave workgroups, 10 computed rows + 2 halo waves, chunks of
+      // about 6 levels (8 in shallower batches), balanced; 3-6 % faster than the row-walking kernel on every device tried
+      // (profiles/r02/experiments/sweep_k3_*.txt).
+      const long tiles = ((rows + 9) / 10) * ((nx + 255) / 256);
+      const int target = prm.nlev >= 48 ? 6 : 8; // levels per chunk; the chunks are then balanced
+      const int nchunks = (prm.nlev + target - 1) / target;
+      if (tiles * nchunks >= kLevelWalkMinUnits) {
+        t.K = 3;
+        t.RB = 12;
+        t.ZZ = 1;
+        t.D = 0;
+        t.LG = (prm.nlev + nchunks - 1) / nchunks;
+      }
     }
     while (t.R > 2 && waves_per_band * ((rows + t.R - 1) / t.R) < 2048)
       t.R /= 2;
@@ -1083,6 +1347,70 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         ONESHOT(true, true, true);
 #undef ONESHOT
       }
+      return hipGetLastError();
+    }
+  }
+  if (t.K == 3 && !rp.fc && prm.op != ST_JACOBIAN && !(rv && dv)) { // level-walking tiles, one output: the default shape only
+    constexpr int NW = 12;
+    rp.uB = (rp.hi - rp.lo + NW - 3) / (NW - 2);
+    rp.uW = (nx + 255) / 256;
+    rp.lgroup = (t.LG > 0 && t.LG < prm.nlev) ? t.LG : prm.nlev;
+    const int nchunks = (prm.nlev + rp.lgroup - 1) / rp.lgroup;
+    const long units = (long)nchunks * rp.uB * rp.uW;
+    if (units <= 0x3fffffffL && (long)nx * (rp.ny_local + 2) < 0x7fffffffL) {
+      rp.n_logical = (int)units;
+      rp.per_xcd = (rp.n_logical + 7) / 8;
+      grid = rp.per_xcd * 8;
+      const bool chk = !prm.every_level_all_defined;
+      if (chk && rv)
+        hipLaunchKernelGGL((vortdiv_levelwalk_kernel<true, true, false, true, NW, 1, true>), dim3(grid), dim3(64 * NW), 0, stream, rp);
+      else if (chk)
+        hipLaunchKernelGGL((vortdiv_levelwalk_kernel<true, false, true, true, NW, 1, true>), dim3(grid), dim3(64 * NW), 0, stream, rp);
+      else if (rv)
+        hipLaunchKernelGGL((vortdiv_levelwalk_kernel<false, true, false, true, NW, 1, true>), dim3(grid), dim3(64 * NW), 0, stream, rp);
+      else
+        hipLaunchKernelGGL((vortdiv_levelwalk_kernel<false, false, true, true, NW, 1, true>), dim3(grid), dim3(64 * NW), 0, stream, rp);
+      return hipGetLastError();
+    }
+  }
+  if (t.K == 3 && !rp.fc && prm.op != ST_JACOBIAN && rv && dv) { // level-walking tiles: units are (level chunk, row block, 256-column segment)
+    const int NWsel = (t.RB == 16 || t.RB == 12 || t.RB == 8) ? t.RB : 16; // RB doubles as the waves per workgroup here
+    const bool halo_waves = t.ZZ != 0;                                     // ZZ doubles as "the halo rows have waves of their own"
+    const int tile_rows = halo_waves ? NWsel - 2 : NWsel;
+    rp.uB = (rp.hi - rp.lo + tile_rows - 1) / tile_rows;
+    rp.uW = (nx + 255) / 256;
+    rp.lgroup = (t.LG > 0 && t.LG < prm.nlev) ? t.LG : prm.nlev; // levels per workgroup
+    const int nchunks = (prm.nlev + rp.lgroup - 1) / rp.lgroup;
+    const long units = (long)nchunks * rp.uB * rp.uW;
+    if (units <= 0x3fffffffL && (long)nx * (rp.ny_local + 2) < 0x7fffffffL) {
+      rp.n_logical = (int)units;
+      rp.per_xcd = (rp.n_logical + 7) / 8;
+      grid = rp.per_xcd * 8;
+      const bool chk = !prm.every_level_all_defined;
+      const int pf = t.D >= 1 ? 2 : 1; // D doubles as the prefetch depth selector: D=0 -> one level ahead, D=1 (default) -> two
+#define LEVELWALK(NW_, PF_)                                                                                                                          \
+  if (chk && halo_waves)                                                                                                                             \
+    hipLaunchKernelGGL((vortdiv_levelwalk_kernel<true, true, true, true, NW_, PF_, true>), dim3(grid), dim3(64 * NW_), 0, stream, rp);               \
+  else if (chk)                                                                                                                                      \
+    hipLaunchKernelGGL((vortdiv_levelwalk_kernel<true, true, true, true, NW_, PF_, false>), dim3(grid), dim3(64 * NW_), 0, stream, rp);              \
+  else if (halo_waves)                                                                                                                               \
+    hipLaunchKernelGGL((vortdiv_levelwalk_kernel<false, true, true, true, NW_, PF_, true>), dim3(grid), dim3(64 * NW_), 0, stream, rp);              \
+  else                                                                                                                                               \
+    hipLaunchKernelGGL((vortdiv_levelwalk_kernel<false, true, true, true, NW_, PF_, false>), dim3(grid), dim3(64 * NW_), 0, stream, rp)
+      if (NWsel == 16 && pf == 2) {
+        LEVELWALK(16, 2);
+      } else if (NWsel == 16) {
+        LEVELWALK(16, 1);
+      } else if (NWsel == 12 && pf == 2) {
+        LEVELWALK(12, 2);
+      } else if (NWsel == 12) {
+        LEVELWALK(12, 1);
+      } else if (pf == 2) {
+        LEVELWALK(8, 2);
+      } else {
+        LEVELWALK(8, 1);
+      }
+#undef LEVELWALK
       return hipGetLastError();
     }
   }

@@ -358,7 +358,9 @@ def _expect_levels(oracle, u, v, xm, ym, flags):
 
 @pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 9), (516, 70, 6), (260, 11, 5), (17, 9, 7), (1440, 75, 5)])
 @pytest.mark.parametrize("tune", ["", "R=7,D=0", "R=5,D=1,NT=1", "R=64,D=1,WPB=8", "K=1", "K=1,XCD=0,NT=0", "K=2", "K=2,XCD=0", "R=1", "R=2,WPB=2", "R=8",
-                                  "K=2,LG=8", "K=2,LG=4,XCD=0", "K=1,LG=3", "K=2,RB=14", "K=2,RB=14,LG=16"])
+                                  "K=2,LG=8", "K=2,LG=4,XCD=0", "K=1,LG=3", "K=2,RB=14", "K=2,RB=14,LG=16",
+                                  "K=3", "K=3,RB=8,LG=2", "K=3,RB=16,LG=4,XCD=0", "K=3,RB=12,LG=1", "K=3,RB=16,LG=3,D=0", "K=3,RB=8,D=0,LG=4",
+                                  "K=3,RB=16,LG=2,D=0,ZZ=1", "K=3,RB=12,D=1,ZZ=1", "K=3,RB=8,LG=5,D=0,ZZ=1,XCD=0"])
 def test_vortdiv_levels_matches_per_level_reference_calls(gpu_ctx, oracle, nx, ny, nlev, tune, mifc_env):
     import torch
 

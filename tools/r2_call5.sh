@@ -1,8 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out/r2
-timeout -k 10 500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scale.py -q -m gpu --maxfail=10 -k "winddir or catalogue or golden or families or pointwise or known or elementwise or python_surface" > gpurun_out/r2/tests_c.log 2>&1
-rc=$?
-tail -12 gpurun_out/r2/tests_c.log
-if [ $rc -ge 124 ]; then exit $rc; fi
-timeout -k 10 600 python tools/bench_ops.py 137 > gpurun_out/r2/bench_ops.txt 2>&1 || { tail -20 gpurun_out/r2/bench_ops.txt; exit 1; }
-grep -v "^{" gpurun_out/r2/bench_ops.txt | tail -70
+B="K=3,RB=12,ZZ=1,D=0"
+for shp in 1440,720,16 1440,720,32 1440,720,64; do
+SWEEP_SHAPE=$shp SWEEP_ROUNDS=7 SWEEP_NO_YARD=1 timeout -k 10 300 python tools/sweep_vortdiv.py "R=8" "$B,LG=2" "$B,LG=3" "$B,LG=4" "$B,LG=6" "$B,LG=8" "K=3,RB=12,ZZ=1,D=1,LG=4" "K=3,RB=8,ZZ=1,D=0,LG=4" > gpurun_out/r2/sweep_k3_lg_$shp.txt 2>&1 || { tail gpurun_out/r2/sweep_k3_lg_$shp.txt; exit 1; }
+head -10 gpurun_out/r2/sweep_k3_lg_$shp.txt
+done
