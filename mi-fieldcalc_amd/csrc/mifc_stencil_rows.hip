@@ -391,9 +391,157 @@ __global__ __launch_bounds__(256) void scalar_oneshot_kernel(const SRowsParams P
     wave_count_add(P.n_undefined + lev, bad);
 }
 
+// Level-walking form for deep batches (same design as vortdiv_levelwalk_kernel, mifc_vortdiv.hip): a workgroup
+// is 12 waves = a tile of 10 rows x 256 columns plus one wave each for the row above and below it; it stays on
+// its tile and walks through a chunk of levels.  The tile's map factors live in registers for the whole walk;
+// per level a wave loads one row of the field (the row of the next level is in flight meanwhile), parks it in
+// one of two LDS buffers, one LDS-only barrier, rows above / below from LDS, x-neighbours by DPP, streaming stores.
+constexpr int LW_WAVES = 12;
+constexpr int LW_ROWS = LW_WAVES - 2;
+
+template <int OP, bool CHECK>
+__global__ __launch_bounds__(64 * LW_WAVES, 6) void scalar_levelwalk_kernel(const SRowsParams P)
+{
+  constexpr bool USE_XM = (OP != ST_GRAD_Y && OP != ST_GWIND_X);
+  constexpr bool USE_YM = (OP != ST_GRAD_X && OP != ST_GWIND_Y);
+  constexpr bool USE_FC = (OP == ST_GWIND_X || OP == ST_GWIND_Y || OP == ST_GVORT || OP == ST_IGWIND);
+  constexpr bool TWO_OUT = (OP == ST_IGWIND);
+  __shared__ v4f sf[2][LW_WAVES][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int bid = blockIdx.x;
+  const int seq = (bid & 7) * P.per_xcd + (bid >> 3);
+  if (seq >= P.n_logical)
+    return;
+  // unit = (level chunk, row block, column segment), column segment fastest
+  const int ntiles = P.uB * P.uW;
+  const int lchunk = seq / ntiles;
+  const int tile = seq - lchunk * ntiles;
+  const int rblock = tile / P.uW;
+  const int wc = tile - rblock * P.uW;
+  const int lev0 = lchunk * P.wpb; // wpb: levels per chunk here
+  const int lev1 = (lev0 + P.wpb < P.nlev) ? lev0 + P.wpb : P.nlev;
+
+  const int nx = P.nx, ny = P.ny;
+  const int first = 1 + rblock * LW_ROWS; // rows 1 .. ny-2 are computed
+  const int j_raw = first + wave - 1;     // LDS slot = wave: slot 0 is the row above the tile
+  const bool computes = wave >= 1 && wave <= LW_ROWS && j_raw <= ny - 2;
+  const int j = j_raw < ny - 1 ? j_raw : ny - 1; // rows past the field: loaded from the last row, never used
+  const int col = wc * 256 + lane * 4;
+  const bool act = col < nx;
+  const int col_c = act ? col : nx - 4;
+  int east_col = wc * 256 + 256;
+  if (east_col > nx)
+    east_col = nx;
+  const int edge_col = (lane == 63) ? east_col : (wc * 256 - 1);
+  const float undef = P.undef;
+  const int base = j * nx; // offsets inside a level fit 32 bits (the launcher checks)
+  const int o = base + col_c;
+  long e64 = (long)base + edge_col;
+  const long idx_hi = (long)nx * ny - 1;
+  e64 = e64 < 0 ? 0 : (e64 > idx_hi ? idx_hi : e64);
+  const int e = (int)e64;
+  const int oo = base + col;
+  const bool last_in_seg = col + 4 >= east_col;
+
+  v4f xm4 = {0.f, 0.f, 0.f, 0.f}, ym4 = xm4, fc4 = xm4;
+  if (computes) {
+    if (USE_XM)
+      xm4 = ld4(P.xm + o);
+    if (USE_YM)
+      ym4 = ld4(P.ym + o);
+    if (USE_FC)
+      fc4 = ld4(P.fc + o);
+  }
+  struct Lev
+  {
+    v4f f;
+    float e;
+  };
+  auto load_level = [&](int lev) -> Lev {
+    const int l = lev < lev1 ? lev : lev1 - 1;
+    const float* __restrict__ f = P.f + (size_t)l * P.in_stride;
+    Lev r;
+    r.f = ld4(f + o);
+    r.e = f[e];
+    return r;
+  };
+  Lev R[2];
+  R[0] = load_level(lev0);
+  for (int lb = lev0; lb < lev1; lb += 2) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int lev = lb + s;
+      if (lev >= lev1)
+        goto chunk_done;
+      R[s ^ 1] = load_level(lev + 1); // in flight while this level is computed
+      const Lev& C = R[s];
+      const int buf = (lev - lev0) & 1;
+      sf[buf][wave][lane] = C.f;
+      // only the LDS counter is waited for: the prefetch above and earlier stores stay in flight.  Two buffers: a
+      // wave can overwrite buffer b again only after the barrier of the level in between.
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (computes) {
+        const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
+        const v4f fn = sf[buf][wave + 1][lane], fs = sf[buf][wave - 1][lane];
+        const float east = lane_value(C.e, 63);
+        const float fW = dpp_lower(C.e, C.f.w);
+        float fE = dpp_upper(C.e, C.f.x);
+        if (last_in_seg)
+          fE = east;
+        const float fc6[6] = {fW, C.f.x, C.f.y, C.f.z, C.f.w, fE};
+        float z0[4], z1[4];
+        unsigned int bad = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float r0 = undef, r1 = undef;
+          const bool ok = scalar_cell<OP, CHECK>(all, undef, fc6[k], fc6[k + 1], fc6[k + 2], fs[k], fn[k], xm4[k], ym4[k], fc4[k], r0, r1);
+          z0[k] = ok ? r0 : undef;
+          z1[k] = ok ? r1 : undef;
+          if (CHECK && !ok && act)
+            bad += 1;
+        }
+        if (col == 0) { // fillEdges, column part
+          z0[0] = z0[1];
+          z1[0] = z1[1];
+        }
+        if (col + 4 == nx) {
+          z0[3] = z0[2];
+          z1[3] = z1[2];
+        }
+        if (act) {
+          float* o0p = P.o0 + (size_t)lev * P.out_stride;
+          st4_stream(o0p + oo, z0);
+          if (j == 1) // fillEdges, row part
+            st4_stream(o0p + oo - nx, z0);
+          if (j == ny - 2)
+            st4_stream(o0p + oo + nx, z0);
+          if (TWO_OUT) {
+            float* o1p = P.o1 + (size_t)lev * P.out_stride;
+            st4_stream(o1p + oo, z1);
+            if (j == 1)
+              st4_stream(o1p + oo - nx, z1);
+            if (j == ny - 2)
+              st4_stream(o1p + oo + nx, z1);
+          }
+        }
+        if (CHECK && P.n_undefined && !all)
+          wave_count_add(P.n_undefined + lev, bad);
+      }
+    }
+  }
+chunk_done:;
+}
+
 template <int OP>
 void launch_op(const SRowsParams& rp, bool check, int V, int grid, size_t lds, hipStream_t stream)
 {
+  if (V == 3) { // level-walking form: rp.uB / rp.uW are 10-row blocks / 256-column segments, rp.wpb the levels per chunk
+    if (check)
+      hipLaunchKernelGGL((scalar_levelwalk_kernel<OP, true>), dim3(grid), dim3(64 * LW_WAVES), 0, stream, rp);
+    else
+      hipLaunchKernelGGL((scalar_levelwalk_kernel<OP, false>), dim3(grid), dim3(64 * LW_WAVES), 0, stream, rp);
+    return;
+  }
   if (V == 0) { // one-shot form: rp.uB / rp.uW are row blocks of 4 / 256-column segments, grid = levels * uB * uW
     if (check)
       hipLaunchKernelGGL((scalar_oneshot_kernel<OP, true>), dim3(grid), dim3(256), 0, stream, rp);
@@ -506,6 +654,28 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
     if (units <= 0x7fffffffL) {
       grid = (int)units;
       form = 0;
+    }
+  }
+
+  // Deep batches: tiles that stay put and walk the levels (see scalar_levelwalk_kernel).  Measured on 1440x720x137
+  // (profiles/r02/experiments/ab_levelwalk_ops.txt): the two one-sided gradients gain 2-5 %, the operators with
+  // more arithmetic per cell (|grad|: a square root; gvort, gwind: f64 divisions) lose 2-16 % -- all waves of a
+  // workgroup compute at the same phase here, while the row-walking waves drift apart and overlap their
+  // arithmetic with each other's memory time.  So only the light ones take this form by default; with
+  // MIFC_LEVELWALK_MIN_UNITS set (tests) every operator does.
+  const bool light = (op == ST_GRAD_X || op == ST_GRAD_Y);
+  if (form != 0 && forced_r < 0 && env().levelwalk && (light || env().levelwalk_min_units > 0) && prm.nlev >= 3 && (long)nx * ny < 0x7fffffffL) {
+    const int target = prm.nlev >= 48 ? 6 : 8; // levels per chunk, then balanced
+    const int nchunks = (prm.nlev + target - 1) / target;
+    const long tiles = (long)((ny - 2 + LW_ROWS - 1) / LW_ROWS) * ((nx + 255) / 256);
+    if (tiles * nchunks >= (env().levelwalk_min_units > 0 ? env().levelwalk_min_units : 768) && tiles * nchunks <= 0x3fffffffL) {
+      rp.uB = (ny - 2 + LW_ROWS - 1) / LW_ROWS;
+      rp.uW = (nx + 255) / 256;
+      rp.wpb = (prm.nlev + nchunks - 1) / nchunks;
+      rp.n_logical = (int)(tiles * ((prm.nlev + rp.wpb - 1) / rp.wpb));
+      rp.per_xcd = (rp.n_logical + 7) / 8;
+      grid = rp.per_xcd * 8;
+      form = 3;
     }
   }
 

@@ -1205,7 +1205,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       const long tiles = ((rows + 9) / 10) * ((nx + 255) / 256);
       const int target = prm.nlev >= 48 ? 6 : 8; // levels per chunk; the chunks are then balanced
       const int nchunks = (prm.nlev + target - 1) / target;
-      if (tiles * nchunks >= kLevelWalkMinUnits) {
+      if (tiles * nchunks >= (env().levelwalk_min_units > 0 ? env().levelwalk_min_units : kLevelWalkMinUnits)) {
         t.K = 3;
         t.RB = 12;
         t.ZZ = 1;

@@ -617,11 +617,18 @@ def test_headline_1440x720x137_properties(gpu_ctx, oracle, mifc_env):
 
 
 # ------------------------------------------------------------------ generic batched stencils
-@pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 5), (260, 21, 4)])
-def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev):
-    """mifc_stencil_levels: each operator over a batch == the per-level reference call, flags included."""
+@pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 5), (260, 21, 4), (520, 25, 7), (1440, 13, 9), (8, 3, 3)])
+@pytest.mark.parametrize("walk", [None, "1"])
+def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc_env):
+    """mifc_stencil_levels: each operator over a batch == the per-level reference call, flags included.
+    walk="1": the level-walking forms (tiles that stay put and walk the levels) are chosen whatever the launch
+    size -- ragged tiles, widths below one segment, chunks of unequal length; device-resident batches then."""
+    import torch
+
     import mi_fieldcalc_amd.synth as synth
 
+    mifc_env("MIFC_LEVELWALK_MIN_UNITS", walk)
+    on_device = walk is not None
     xm, ym, fcor = synth.grid_maps(nx, ny)
     u, v = synth.wind(nx, ny, 606 + nx, nlev=nlev)
     z = np.stack([synth.scalar_field(nx, ny, 700 + l) for l in range(nlev)])
@@ -640,10 +647,14 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev):
         ("plevelgvort", "plevelgvort", z, None, True, None, []), ("ilevelgwind", "ilevelgwind", z, None, True, None, []),
         ("jacobian", "jacobian", z, u, False, None, []),
     ]
+    dev = (lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()) if on_device else (lambda a: a)
+    host = (lambda a: None if a is None else a.cpu().numpy()) if on_device else (lambda a: a)
+    dxm, dym, dfc = dev(xm), dev(ym), dev(fcor)
     for name, cpu_op, f0, f1, use_fc, compute, _ in table:
-        res = gpu_ctx.stencil_levels(name, f0, f1, xm, ym, fcor if use_fc else None, fdefined=flags)
+        res = gpu_ctx.stencil_levels(name, dev(f0), dev(f1), dxm, dym, dfc if use_fc else None, fdefined=flags)
         assert res is not None, name
         (o0, o1), fo = res
+        o0, o1 = host(o0), host(o1)
         for l in range(nlev):
             if name == "vortdiv":
                 ok, e0, f_e = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=int(flags[l]))
