@@ -393,6 +393,8 @@ int mifc_showalterIndex(mifc_ctx* c, int nx, int ny, const float* t500, const fl
   }
   pc.P.s[3] = p500;
   pc.P.s[4] = p850;
+  pc.P.d[0] = 1.0 / (double)K_CP; // the kernel's float divisions by cp and p500 as double multiplications (see PW_SHOWALTER)
+  pc.P.d[1] = (p500 > 1e-6f && p500 < 1e9f) ? 1.0 / (double)p500 : 0.0;
   pc.P.skip_undefined_input = 1; // :965-967: counted, cell not written
   pc.P.may_keep = 1;
   pc.in[0] = t500;

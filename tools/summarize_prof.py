@@ -40,8 +40,8 @@ def main():
             if line.startswith("{") and '"roofline"' in line:
                 try:
                     d = json.loads(line)
-                    print("== bench.py inside the traced process: %.1f Mcells/s, kernel %.4f ms avg / %.4f ms min by HIP events over %d timed steps"
-                          % (d["value"], d["roofline"]["kernel_ms_avg"], d["roofline"]["kernel_ms_min"], d["steps"]))
+                    print("== bench.py inside the traced process: %.1f Mcells/s, kernel %.4f ms avg by HIP events around %d timed steps (single launches between their own event pairs: median %.4f)"
+                          % (d["value"], d["roofline"]["kernel_ms_avg"], d["steps"], d["roofline"]["per_launch_event_pairs_ms"]["median"]))
                 except (ValueError, KeyError):
                     pass
     # ---- counters: average per dispatch of the headline kernel
