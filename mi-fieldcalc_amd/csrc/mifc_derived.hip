@@ -81,7 +81,7 @@ __device__ __forceinline__ bool hum_point(int code, const float* tab, float tt, 
 template <bool CHECK, int FF, int TC, int HC, int DC, bool PIPE = true>
 __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams P)
 {
-  __shared__ float s_ewt[MIFC_EWT_LDS];
+  __shared__ __attribute__((aligned(8))) float s_ewt[MIFC_EWT_LDS];
   __shared__ double s_pow[MIFC_KAPPA_LDS];
 
   const bool want_ff = FF >= 0 ? (FF != 0) : (P.ff != nullptr);

@@ -32,7 +32,9 @@ typedef unsigned long long u64;
 // LDS copy of the table: the 41 values, then 26 start indices for the inverse lookup (one per
 // binary exponent of the argument, see Ewt::inverse)
 #define MIFC_EWT_FIRST_N 26
-#define MIFC_EWT_LDS (MIFC_N_EWT + MIFC_EWT_FIRST_N)
+// floats of LDS: ewt[41], first[26], one pad, then 41 doubles: 1 / (ewt[k+1] - ewt[k]) (the table must be 8-byte aligned)
+#define MIFC_EWT_RCP_AT (MIFC_N_EWT + MIFC_EWT_FIRST_N + 1)
+#define MIFC_EWT_LDS (MIFC_EWT_RCP_AT + 2 * MIFC_N_EWT)
 
 // FieldCalculations.h:42-45
 __device__ __forceinline__ bool is_def(float x, float undef)
@@ -63,6 +65,10 @@ __device__ __forceinline__ void ewt_table_init(float* lds_tab)
     lds_tab[k] = init[k];
   for (int k = threadIdx.x; k < MIFC_EWT_FIRST_N; k += blockDim.x)
     lds_tab[MIFC_N_EWT + k] = __int_as_float(first[k]);
+  // reciprocals of the bin widths, for the division of the inverse lookup (see Ewt::inverse)
+  double* rcp = reinterpret_cast<double*>(lds_tab + MIFC_EWT_RCP_AT);
+  for (int k = threadIdx.x; k < MIFC_N_EWT; k += blockDim.x)
+    rcp[k] = k + 1 < MIFC_N_EWT ? 1.0 / (double)(init[k + 1] - init[k]) : 0.0;
   __syncthreads();
 }
 
@@ -109,7 +115,11 @@ struct Ewt
       m = MIFC_N_EWT - 1;
     const int ll = m < l ? m : l;
 #endif
-    const float r = (et - tab[ll]) / (tab[ll + 1] - tab[ll]);
+    // (et - ewt[ll]) / (ewt[ll+1] - ewt[ll]): a quotient of two floats is never closer than 2^-49 (relative) to a
+    // rounding boundary of float, so the double product with the correctly rounded reciprocal of the bin width
+    // (off by < 2^-52), rounded to float, IS the correctly rounded float quotient -- 4 instructions instead of 12
+    const double* rcp = reinterpret_cast<const double*>(tab + MIFC_EWT_RCP_AT);
+    const float r = (float)((double)(et - tab[ll]) * rcp[ll]);
     return (float)(-100. + (double)((float)ll + r) * 5.);
   }
 };

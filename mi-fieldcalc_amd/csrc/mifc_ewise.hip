@@ -170,7 +170,7 @@ __host__ __device__ inline bool ewise_needs_pow(const EwiseParams& P)
 template <int OP, bool VEC4>
 __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
 {
-  __shared__ float s_ewt[MIFC_EWT_LDS];
+  __shared__ __attribute__((aligned(8))) float s_ewt[MIFC_EWT_LDS];
   constexpr bool USES_POW = (OP == EW_TEMP || OP == EW_TEMP_PLAIN || OP == EW_HUM || OP == EW_HUM_DIRECT);
   __shared__ double s_pow[USES_POW ? MIFC_KAPPA_LDS : 1];
   // the lookup tables cost a few hundred cycles per workgroup: staged only

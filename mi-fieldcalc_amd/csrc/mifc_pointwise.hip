@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
 {
   constexpr int NIN = PwTraits<OP>::nin;
   constexpr int NV = NIN > 0 ? NIN : 1;
-  __shared__ float s_ewt[PwTraits<OP>::ewt ? MIFC_EWT_LDS : 1];
+  __shared__ __attribute__((aligned(8))) float s_ewt[PwTraits<OP>::ewt ? MIFC_EWT_LDS : 2];
   // x^kappa tables (theta-e, ducting from theta) or the generic log2 / exp2 tables (the libm-class functions)
   __shared__ double s_pow[PwTraits<OP>::pow == 2 ? MIFC_KAPPA_LDS : (PwTraits<OP>::pow == 1 ? (2 * MIFC_POW_LOG_N + MIFC_POW_EXP_N) : 1)];
   PowTables PT = {s_pow, s_pow, s_pow, s_pow};
