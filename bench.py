@@ -211,6 +211,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison with the CPU reference path before timing (profiling runs)")
     ap.add_argument("--no-check-variant", action="store_true", help="do not time the SOME_DEFINED (per-cell tests + counts) variant")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the tested variant is timed by default)")
+    ap.add_argument("--settle-ms", type=float, default=40.0, help="untimed launches for this long before the W warm-up steps (clock ramp after idle); 0 = none")
     ap.add_argument("--placement-tries", type=int, default=6,
                     help="candidate placements of the batch in HBM, the fastest is kept (mi-fieldcalc_amd/placement.py); 1 = take the first allocation")
     ap.add_argument("--level-stride", type=int, default=None, help="floats between levels (default: the library's mifc_batch_level_stride)")
@@ -353,6 +354,14 @@ def main():
             du[l, 100:110, 200:260] = blk
         verified = True
 
+    # The first ~15 ms of GPU work after an idle stretch (the verification above copies levels to the host and
+    # runs the CPU reference) run 2-3 % slower (profiles/r02/experiments/time_series.txt): W steps of 0.4 ms do
+    # not cover that, so the W warm-up steps are preceded by untimed launches until --settle-ms have passed.
+    t_settle = time.perf_counter()
+    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
