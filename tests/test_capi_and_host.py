@@ -354,3 +354,33 @@ def test_environment_is_read_in_one_place_only():
         if f.endswith((".hip", ".h")) and f != "mifc_env.hip":
             code = re.sub(r"//.*", "", open(os.path.join(csrc, f)).read())
             assert "getenv" not in code, f
+
+
+def test_choose_placement_keeps_the_fastest_candidate():
+    """placement.choose_placement: every candidate is allocated and probed once, the fastest is returned,
+    the report names it; the losers are released."""
+    import gc
+    import weakref
+
+    from mi_fieldcalc_amd.placement import choose_placement
+
+    class Cand:
+        def __init__(self, k):
+            self.k = k
+
+    made, refs = [], []
+    times = [3.0, 1.5, 2.0, 1.7]
+
+    def allocate():
+        c = Cand(len(made))
+        made.append(c.k)
+        refs.append(weakref.ref(c))
+        return c
+
+    best, report = choose_placement(allocate, lambda c: times[c.k], tries=4, device="cpu")
+    assert made == [0, 1, 2, 3] and best.k == 1
+    assert report == {"tries": 4, "probe_ms": times, "chosen": 1}
+    gc.collect()
+    assert [r() is not None for r in refs] == [False, True, False, False]
+    with pytest.raises(ValueError):
+        choose_placement(allocate, lambda c: 0.0, tries=0)
