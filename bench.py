@@ -212,7 +212,7 @@ def main():
     ap.add_argument("--no-check-variant", action="store_true", help="do not time the SOME_DEFINED (per-cell tests + counts) variant")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the tested variant is timed by default)")
     ap.add_argument("--settle-ms", type=float, default=40.0, help="untimed launches for this long before the W warm-up steps (clock ramp after idle); 0 = none")
-    ap.add_argument("--placement-tries", type=int, default=6,
+    ap.add_argument("--placement-tries", type=int, default=12,
                     help="candidate placements of the batch in HBM, the fastest is kept (mi-fieldcalc_amd/placement.py); 1 = take the first allocation")
     ap.add_argument("--level-stride", type=int, default=None, help="floats between levels (default: the library's mifc_batch_level_stride)")
     args = ap.parse_args()

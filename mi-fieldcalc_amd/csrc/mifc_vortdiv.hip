@@ -819,6 +819,8 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
   const bool last_in_seg = col + 4 >= east_col;
   const int oo = base + col;
 
+  // rows 2 .. TR-1 of a tile are read by this workgroup only (rows 1 and TR are the neighbours' halo rows)
+  const bool stream_rows = HALO && P.nt_interior && wave >= 2 && wave <= TR - 1;
   // the tile's map factors: once, for every level of the chunk
   v4f xm4 = {0.f, 0.f, 0.f, 0.f}, ym4 = xm4;
   if (computes) {
@@ -856,8 +858,13 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
       return r;
     }
 #endif
-    r.u = load4(u + o);
-    r.v = load4(v + o);
+    if (stream_rows) { // no other workgroup reads this row: do not keep it in L2, where the shared boundary rows should stay
+      r.u = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(u + o));
+      r.v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v + o));
+    } else {
+      r.u = load4(u + o);
+      r.v = load4(v + o);
+    }
     if constexpr (!HALO) {
       r.xu = r.u;
       r.xv = r.v;
