@@ -1,5 +1,13 @@
 """Choosing WHERE in HBM a long-lived batch lives.
 
+Second finding (profiles/r02/experiments/placement_spacing.txt, placement_search.txt,
+arena_distance_sweep.txt): what makes a placement slow is that the arrays a kernel streams
+concurrently lie CLOSE to each other in physical memory.  Arrays allocated one after the other (544 MiB
+apart for the headline batch), or carved out of one allocation at any distance up to 2.5 GiB, run the
+operator in 0.43-0.44 ms; the same operator on arrays that were allocated 6 or more arrays apart (>= 3 GiB)
+runs in 0.385-0.395 ms, reproducibly.  choose_spread() therefore allocates a pool of arrays in one go, takes
+arrays that lie `spacing` allocations apart, probes a few such index sets and frees the rest of the pool.
+
 Measured on MI355X (profiles/r02/experiments/alloc_variance.txt, arena_variance.txt, time_series.txt):
 the time of a streaming kernel over the same arrays is stable to 0.3 % for as long as the arrays stay
 where they are, but changes by 3-9 % when they are freed and allocated again -- even at the same
@@ -38,3 +46,40 @@ def choose_placement(allocate, probe, tries=6, device=None, spacers_mib=SPACERS_
     if torch.cuda.is_available():
         torch.cuda.empty_cache()
     return chosen, {"tries": tries, "probe_ms": [round(t, 4) for t in ms], "chosen": best}
+
+
+def choose_spread(allocate_array, n_arrays, probe, spacing=11, extra=4, max_candidates=8, device=None):
+    """allocate_array() -> one freshly allocated device array of the batch (called (n_arrays-1)*(spacing+1)+1+extra
+    times in a row; the whole pool is alive at once, everything but the chosen arrays is freed at the end);
+    probe(tuple of n_arrays arrays) -> milliseconds of a representative kernel on them, in the kernel's argument
+    order (values in the arrays do not matter to the time; fill the chosen ones afterwards).
+    Candidates are the index sets (b, b+s, b+2s, ...) for s in (spacing, spacing+1) and the bases b that fit,
+    at most max_candidates of them, plus -- for the record -- the first n_arrays arrays of the pool, i.e. what
+    allocating the batch in one go would have given.
+    Returns (tuple of the chosen arrays, report dict)."""
+    if n_arrays < 1 or spacing < 1:
+        raise ValueError("n_arrays and spacing must be >= 1")
+    size = (n_arrays - 1) * (spacing + 1) + 1 + max(0, extra)
+    pool = [allocate_array() for _ in range(size)]
+    cands = []
+    for s in (spacing, spacing + 1):
+        for b in range(0, size - (n_arrays - 1) * s):
+            cands.append(tuple(b + k * s for k in range(n_arrays)))
+    # spread the candidates over bases and both spacings
+    step = max(1, len(cands) // max(1, max_candidates))
+    cands = cands[::step][:max_candidates]
+    adjacent = tuple(range(n_arrays))
+    ms_adjacent = float(probe(tuple(pool[i] for i in adjacent))) if size >= n_arrays else None
+    ms = [float(probe(tuple(pool[i] for i in c))) for c in cands]
+    best = min(range(len(cands)), key=lambda i: ms[i])
+    if ms_adjacent is not None and ms_adjacent < ms[best]:
+        chosen_idx, chosen_ms = adjacent, ms_adjacent
+    else:
+        chosen_idx, chosen_ms = cands[best], ms[best]
+    chosen = tuple(pool[i] for i in chosen_idx)
+    del pool
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    return chosen, {"method": "arrays %d allocations apart, pool of %d" % (spacing, size), "candidates": [list(c) for c in cands],
+                    "probe_ms": [round(t, 4) for t in ms], "allocated_in_one_go_ms": None if ms_adjacent is None else round(ms_adjacent, 4),
+                    "chosen": list(chosen_idx), "chosen_ms": round(chosen_ms, 4)}
