@@ -212,9 +212,10 @@ def main():
     ap.add_argument("--no-check-variant", action="store_true", help="do not time the SOME_DEFINED (per-cell tests + counts) variant")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the tested variant is timed by default)")
     ap.add_argument("--settle-ms", type=float, default=40.0, help="untimed launches for this long before the W warm-up steps (clock ramp after idle); 0 = none")
-    ap.add_argument("--placement-spacing", type=int, default=11,
-                    help="the four arrays of the batch are taken this many allocations apart from a pool (mi-fieldcalc_amd/placement.py); 0 = four allocations as they come")
-    ap.add_argument("--placement-tries", type=int, default=8, help="index sets of the pool that are probed, the fastest is kept")
+    ap.add_argument("--placement-pool", type=int, default=24,
+                    help="the four arrays of the batch are chosen from a pool of this many arrays allocated in one go (mi-fieldcalc_amd/placement.py: which "
+                         "combination of arrays a kernel streams decides its time by up to 12 %%); 0 = four allocations as they come")
+    ap.add_argument("--placement-tries", type=int, default=160, help="probes (index sets of the pool timed with the kernel) the search may spend; the fastest set is kept")
     ap.add_argument("--level-stride", type=int, default=None, help="floats between levels (default: the library's mifc_batch_level_stride)")
     args = ap.parse_args()
 
@@ -256,7 +257,7 @@ def main():
     counts = torch.zeros(NLEV, dtype=torch.int64, device=dev)
     su, sv = synth.device_wind(NX, NY, NLEV, SEED + 17 * rank, dev)
 
-    def probe_batch(arrays):  # median of 5 x 4 launches of the kernel the bench times
+    def probe_batch(arrays):  # median of 3 x 4 launches of the kernel the bench times
         a, b, c, d = arrays
         if not warmed:  # the first launches of a process run 2-3 % slower for ~15 ms (time_series.txt): not a property of the placement
             for _ in range(60):
@@ -264,7 +265,7 @@ def main():
             torch.cuda.synchronize()
             warmed.append(True)
         ms = []
-        for k in range(6):
+        for k in range(4):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             for _ in range(4):
@@ -276,17 +277,17 @@ def main():
                 ms.append(s.elapsed_time(e) / 4)
         return float(np.median(ms))
 
-    # Where the four arrays of the batch lie in HBM changes a streaming kernel's time by up to 12 % (stable once
-    # allocated; arrays that are close to each other in physical memory are the slow case: DESIGN.md 4.1,
-    # mi-fieldcalc_amd/placement.py).  A long-lived batch is therefore taken from a pool of arrays allocated in one
-    # go, arrays `--placement-spacing` allocations apart, the fastest of a few such sets; the rest of the pool is
-    # freed.  Outside every timed region; the report (incl. what the first four arrays of the pool -- "allocated in
-    # one go" -- would have given) goes into the JSON line.  --placement-spacing 0: take four allocations as they come.
+    # Which physical pages the four arrays of the batch lie on changes a streaming kernel's time by up to 12 % (stable
+    # once allocated, bimodal -- 0.40 / 0.435 ms -- and a property of the COMBINATION of arrays: DESIGN.md 4.1,
+    # mi-fieldcalc_amd/placement.py).  A long-lived batch is therefore chosen from a pool of arrays allocated in one go:
+    # structured and random index sets are probed with the kernel, then coordinate descent from the best; the rest of
+    # the pool is freed.  Outside every timed region; the report (incl. what the first four arrays of the pool --
+    # "allocated in one go" -- would have given) goes into the JSON line.  --placement-pool 0: four allocations as they come.
     warmed = []
-    from mi_fieldcalc_amd.placement import choose_spread
-    if args.placement_spacing > 0:
-        (du, dv, rv, dg), placement = choose_spread(lambda: ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride), 4, probe_batch,
-                                                    spacing=args.placement_spacing, max_candidates=max(1, args.placement_tries), device=dev)
+    from mi_fieldcalc_amd.placement import choose_search
+    if args.placement_pool >= 4:
+        (du, dv, rv, dg), placement = choose_search(lambda: ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride), 4, probe_batch,
+                                                    pool_size=args.placement_pool, max_probes=max(1, args.placement_tries), device=dev)
     else:
         du, dv, rv, dg = (ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride) for _ in range(4))
         placement = {"method": "four allocations as they come"}

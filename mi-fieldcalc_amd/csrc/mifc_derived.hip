@@ -201,15 +201,16 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
         }
         if (want_h) { // hlevelhum :1186-1213
           float r = 0.f;
-          bool ok = thermo_all || (is_def(tt, undef) && is_def(hh, undef) && (!h_need_p || ss != undef));
-          ok = ok && hum_point(hc, s_ewt, tt, hh, h_need_p ? p : 0.f, pidcp, P.hum_tdconv, r);
+          // the point function runs unconditionally (branch-free: its table reads are clamped), the tests only select
+          const bool okp = hum_point(hc, s_ewt, tt, hh, h_need_p ? p : 0.f, pidcp, P.hum_tdconv, r);
+          const bool ok = (thermo_all || (is_def(tt, undef) && is_def(hh, undef) && (!h_need_p || ss != undef))) && okp;
           rh[k] = ok ? r : undef;
           bad_h += ok ? 0u : 1u;
         }
         if (want_d) {
           float r = 0.f;
-          bool ok = thermo_all || (is_def(tt, undef) && is_def(hh, undef) && (!d_need_p || ss != undef));
-          ok = ok && hum_point(dc, s_ewt, tt, hh, d_need_p ? p : 0.f, pidcp, P.td_tdconv, r);
+          const bool okp = hum_point(dc, s_ewt, tt, hh, d_need_p ? p : 0.f, pidcp, P.td_tdconv, r);
+          const bool ok = (thermo_all || (is_def(tt, undef) && is_def(hh, undef) && (!d_need_p || ss != undef))) && okp;
           rd[k] = ok ? r : undef;
           bad_d += ok ? 0u : 1u;
         }

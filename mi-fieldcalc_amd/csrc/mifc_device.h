@@ -76,15 +76,19 @@ struct Ewt
 {
   float x;
   int l;
+  int lc; // l brought into the table: what the lookups index with, so that they need no branch around them --
+          // every point function below computes unconditionally and reports ok(); a caller discards the value of
+          // a cell that is not ok (the reference: cell := undef, n_undefined += 1).  lc == l whenever ok().
   __device__ __forceinline__ explicit Ewt(float t_celsius)
   {
     x = (float)(((double)t_celsius + 100.) * 0.2); // MetConstants.h:65
     // int(x): the compiled reference (x86-64 cvttss2si) yields INT_MIN for NaN
     // and out-of-range values; v_cvt_i32_f32 would give 0 / saturate.
     l = (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : (int)0x80000000;
+    lc = l < 0 ? 0 : (l > MIFC_N_EWT - 2 ? MIFC_N_EWT - 2 : l);
   }
   __device__ __forceinline__ bool ok() const { return l >= 0 && l < MIFC_N_EWT - 1; }
-  __device__ __forceinline__ float value(const float* tab) const { return tab[l] + (tab[l + 1] - tab[l]) * (x - (float)l); }
+  __device__ __forceinline__ float value(const float* tab) const { return tab[lc] + (tab[lc + 1] - tab[lc]) * (x - (float)lc); }
   // MetConstants.cc:37-45: `ll = l; while (ll > 0 && ll < 40 && ewt[ll] > et) ll--;` -- a walk
   // down the (strictly increasing) table whose length differs from lane to lane.  The same ll
   // without a loop: the walk stops at the largest k <= l for which !(ewt[k] > et) holds, or at
@@ -94,7 +98,7 @@ struct Ewt
   __device__ __forceinline__ float inverse(const float* tab, float et) const
   {
 #ifdef MIFC_EWT_INVERSE_WALK
-    int ll = l;
+    int ll = lc;
     while (ll > 0 && ll < MIFC_N_EWT - 1 && tab[ll] > et)
       ll--;
 #else
@@ -113,7 +117,7 @@ struct Ewt
     }
     if (et != et)
       m = MIFC_N_EWT - 1;
-    const int ll = m < l ? m : l;
+    const int ll = m < lc ? m : lc;
 #endif
     // (et - ewt[ll]) / (ewt[ll+1] - ewt[ll]): a quotient of two floats is never closer than 2^-49 (relative) to a
     // rounding boundary of float, so the double product with the correctly rounded reciprocal of the bin width
@@ -152,7 +156,7 @@ __device__ __forceinline__ float clamp_rh(float rh)
 // (BASELINE.json), not bit-exact.  The fused multiply-adds are explicit here
 // (accuracy, not parity, matters).  Arguments outside [2^-32, 2^32) -- no pressure
 // is -- and special values behave like powf with a positive non-integer exponent:
-// x<0 -> NaN, 0 -> 0, inf -> inf, NaN -> NaN (generic slow path, out of line).
+// x<0 -> NaN, 0 -> 0, inf -> inf, NaN -> NaN (pow_kappa_rare, inline).
 #include "mifc_kappa_tables.h"
 #define MIFC_POW_LOG_N 16
 #define MIFC_POW_EXP_N 32
@@ -226,11 +230,6 @@ __device__ __forceinline__ PowTables kappa_tables_init(double* lds_tab /* MIFC_K
   return t;
 }
 
-__device__ __attribute__((noinline)) float pow_kappa_slow(float x)
-{
-  return (float)exp2((double)MIFC_K_KAPPA * log2((double)x));
-}
-
 // log2 of a positive NORMAL float, in double.  Absolute error ~5e-12 (table of 16 centres, |r| <= 1/32,
 // series to r^6), i.e. fine as the inner function of a power; functions that return the logarithm itself
 // use log2_near_one() around 1, where the RELATIVE error matters.
@@ -277,12 +276,10 @@ __device__ __forceinline__ double exp2_tab(const PowTables& T, double t)
   return ldexp(T.expt[ki & 31] * q, ki >> 5);
 }
 
-__device__ __forceinline__ float pow_kappa(const PowTables& T, float x)
+// x^kappa in double for the bits of a float in [2^-32, 2^32)
+__device__ __forceinline__ double pow_kappa_core(const PowTables& T, int ix)
 {
-  if (!(x >= 2.3283064365386963e-10f /* 2^-32 */ && x < 4294967296.0f /* 2^32 */))
-    return pow_kappa_slow(x);
-  const int ix = __float_as_int(x);
-  const int e = (ix >> 23) - 127; // x is positive and normal here
+  const int e = (ix >> 23) - 127;
   const int i = (ix >> 15) & 0xff;
   const double m = (double)__int_as_float((ix & 0x007fffff) | 0x3f800000);
   const double r = fma(m, T.kit[2 * i], -1.0);
@@ -290,7 +287,47 @@ __device__ __forceinline__ float pow_kappa(const PowTables& T, float x)
   p = fma(p, r, MIFC_KAPPA_K2);
   p = fma(p, r, MIFC_KAPPA_K1);
   p = fma(p, r, 1.0);
-  return (float)(T.ket[e - MIFC_KAPPA_EMIN] * T.kit[2 * i + 1] * p);
+  return T.ket[e - MIFC_KAPPA_EMIN] * T.kit[2 * i + 1] * p;
+}
+// The arguments outside [2^-32, 2^32) -- no pressure is; what reaches here are undefined cells a tested kernel
+// computes and discards -- inline and without a function call: a call inside a kernel's main loop makes the
+// compiler wait for EVERY outstanding load at the loop head (s_waitcnt vmcnt(0): the counters are unknown after a
+// call), which silently undid the two-trip software pipeline of the fused derived kernel.  A finite positive x is
+// brought into the table's range by exact scalings with 2^+-64, 2^(+-64 kappa) multiplied back in double.
+__device__ __forceinline__ float pow_kappa_rare(const PowTables& T, float x)
+{
+  if (x != x || x < 0.f)
+    return __int_as_float(0x7fc00000);
+  if (x == 0.f)
+    return 0.f;
+  if (x == __int_as_float(0x7f800000))
+    return x;
+  float xs;
+  double c;
+  if (x < 1.f) {
+    xs = x * 0x1p64f;
+    c = 0x1.a15e6ebf53f28p-19; // 2^(-64 kappa)
+    if (xs < 2.3283064365386963e-10f) {
+      xs *= 0x1p64f;
+      c = 0x1.543a63d069f35p-37; // 2^(-128 kappa)
+    }
+  } else {
+    xs = x * 0x1p-64f;
+    c = 0x1.3a0b257a9f5abp+18; // 2^(64 kappa)
+    if (xs >= 4294967296.0f) {
+      xs *= 0x1p-64f;
+      c = 0x1.813f586d0cf0ep+36; // 2^(128 kappa)
+    }
+  }
+  return (float)(pow_kappa_core(T, __float_as_int(xs)) * c);
+}
+__device__ __forceinline__ float pow_kappa(const PowTables& T, float x)
+{
+  const bool fast = x >= 2.3283064365386963e-10f /* 2^-32 */ && x < 4294967296.0f /* 2^32 */;
+  float out = (float)pow_kappa_core(T, __float_as_int(fast ? x : 1.f)); // unconditional: the table reads stay in range
+  if (__builtin_expect(!fast, 0))
+    out = pow_kappa_rare(T, x);
+  return out;
 }
 
 // ---- the float libm functions of the catalogue (logf, log10f, expf, powf and the double exp / pow the
@@ -378,67 +415,55 @@ __device__ __forceinline__ double quotient(double a, double b, double y /* share
 __device__ __forceinline__ bool t_thesat(const float* tab, float tk, float p, float pi, float& out)
 {
   Ewt e(tk - MIFC_K_T0);
-  if (!e.ok())
-    return false;
   const float qsat = MIFC_K_EPS * e.value(tab) / p;
   out = (MIFC_K_CP * tk + MIFC_K_XLH * qsat) / pi;
-  return true;
+  return e.ok();
 }
 // FieldCalculations.cc:207-216
 __device__ __forceinline__ bool th_thesat(const float* tab, float th, float p, float pi, float& out)
 {
   Ewt e(th * pi / MIFC_K_CP - MIFC_K_T0);
-  if (!e.ok())
-    return false;
   const float qsat = MIFC_K_EPS * e.value(tab) / p;
   out = th + MIFC_K_XLH * qsat / pi;
-  return true;
+  return e.ok();
 }
 // FieldCalculations.cc:218-227
 __device__ __forceinline__ bool tk_q_rh(const float* tab, float tk, float q, float p, float& out)
 {
   Ewt e(tk - MIFC_K_T0);
-  if (!e.ok())
-    return false;
   const float qsat = MIFC_K_EPS * e.value(tab) / p;
   // 100. * q / qsat in double: the division through the refined reciprocal -- for float-born operands it IS the
   // f64 division, bit for bit (see shared_reciprocal above; mifc_diag_division checks it), three instructions shorter
   const double d = (double)qsat;
   out = (float)quotient(100. * (double)q, d, shared_reciprocal(d));
-  return true;
+  return e.ok();
 }
 // FieldCalculations.cc:229-238
 __device__ __forceinline__ bool tk_rh_q(const float* tab, float tk, float rh, float p, float& out)
 {
   Ewt e(tk - MIFC_K_T0);
-  if (!e.ok())
-    return false;
   const float qsat = MIFC_K_EPS * e.value(tab) / p;
   out = (float)(0.01 * (double)rh * (double)qsat);
-  return true;
+  return e.ok();
 }
 // FieldCalculations.cc:240-253
 __device__ __forceinline__ bool tk_q_td(const float* tab, float tk, float q, float p, float tdconv, float& out)
 {
   Ewt e(tk - MIFC_K_T0);
-  if (!e.ok())
-    return false;
   const float et = e.value(tab);
   const float qsat = MIFC_K_EPS * et / p;
   const float rh = clamp_rh(q / qsat);
   out = e.inverse(tab, rh * et) + tdconv;
-  return true;
+  return e.ok();
 }
 // FieldCalculations.cc:255-267
 __device__ __forceinline__ bool tk_rh_td(const float* tab, float tk, float rh100, float tdconv, float& out)
 {
   Ewt e(tk - MIFC_K_T0);
-  if (!e.ok())
-    return false;
   const float et = e.value(tab);
   const float rh = clamp_rh((float)(0.01 * (double)rh100));
   out = e.inverse(tab, rh * et) + tdconv;
-  return true;
+  return e.ok();
 }
 
 // math_util.h:57-60: sqrt(x*x + y*y) in float, correctly rounded sqrt, no fma

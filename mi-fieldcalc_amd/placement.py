@@ -83,3 +83,65 @@ def choose_spread(allocate_array, n_arrays, probe, spacing=11, extra=4, max_cand
     return chosen, {"method": "arrays %d allocations apart, pool of %d" % (spacing, size), "candidates": [list(c) for c in cands],
                     "probe_ms": [round(t, 4) for t in ms], "allocated_in_one_go_ms": None if ms_adjacent is None else round(ms_adjacent, 4),
                     "chosen": list(chosen_idx), "chosen_ms": round(chosen_ms, 4)}
+
+
+def choose_search(allocate_array, n_arrays, probe, pool_size=24, random_sets=24, max_probes=160, seed=5, good_enough_ms=None, device=None):
+    """Third form (profiles/r02/experiments/placement_search.txt): which COMBINATION of arrays a kernel streams
+    decides its time (no single array and no pair predicts it), candidates spread bimodally (0.40 / 0.435 ms for
+    the headline batch), and in some processes none of a handful of structured candidates is a fast one.  So:
+    a pool of `pool_size` arrays allocated in one go; probe the first n_arrays ("allocated in one go", for the
+    record), the sets that lie pool_size // n_arrays allocations apart and `random_sets` random index sets; then
+    coordinate descent from the best -- replace one array of the set at a time by every other array of the pool,
+    keep what is faster -- until `max_probes` probes are spent, a full sweep brings nothing or the time is at or
+    below `good_enough_ms`.  Everything but the chosen arrays is freed.
+    probe(tuple of n_arrays arrays) -> milliseconds, in the kernel's argument order (values do not matter).
+    Returns (tuple of the chosen arrays, report dict)."""
+    import random
+
+    if n_arrays < 1 or pool_size < n_arrays:
+        raise ValueError("pool_size must be >= n_arrays >= 1")
+    pool = [allocate_array() for _ in range(pool_size)]
+    seen = {}
+
+    def timed(idx):
+        idx = tuple(idx)
+        if idx not in seen:
+            seen[idx] = float(probe(tuple(pool[i] for i in idx)))
+        return seen[idx]
+
+    adjacent = tuple(range(n_arrays))
+    ms_adjacent = timed(adjacent)
+    step = pool_size // n_arrays
+    for b in range(step):
+        timed(tuple(b + k * step for k in range(n_arrays)))
+    rng = random.Random(seed)
+    for _ in range(random_sets):
+        if len(seen) >= max_probes:
+            break
+        timed(tuple(rng.sample(range(pool_size), n_arrays)))
+    best = min(seen, key=seen.get)
+    first_phase = len(seen)
+    improved = True
+    while improved and len(seen) < max_probes and not (good_enough_ms is not None and seen[best] <= good_enough_ms):
+        improved = False
+        for pos in list(range(n_arrays // 2, n_arrays)) + list(range(n_arrays // 2)):  # outputs first: the stores are the slower side
+            cur = list(best)
+            for i in range(pool_size):
+                if i in cur or len(seen) >= max_probes:
+                    continue
+                c = list(cur)
+                c[pos] = i
+                if timed(c) < seen[best]:
+                    best = tuple(c)
+                    improved = True
+            if good_enough_ms is not None and seen[best] <= good_enough_ms:
+                break
+    confirm = float(probe(tuple(pool[i] for i in best)))
+    chosen = tuple(pool[i] for i in best)
+    times = sorted(seen.values())
+    del pool
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    return chosen, {"method": "search over index sets of a pool of %d arrays: %d structured/random sets, then coordinate descent" % (pool_size, first_phase),
+                    "probes": len(seen), "allocated_in_one_go_ms": round(ms_adjacent, 4), "probe_ms_min_median_max": [round(times[0], 4), round(times[len(times) // 2], 4), round(times[-1], 4)],
+                    "chosen": list(best), "chosen_ms": round(seen[best], 4), "chosen_reprobed_ms": round(confirm, 4)}

@@ -384,3 +384,36 @@ def test_choose_placement_keeps_the_fastest_candidate():
     assert [r() is not None for r in refs] == [False, True, False, False]
     with pytest.raises(ValueError):
         choose_placement(allocate, lambda c: 0.0, tries=0)
+
+
+def test_choose_search_finds_the_fast_combination():
+    """placement.choose_search: the time is a property of the COMBINATION (here: fast only when the two outputs are
+    a particular pair and the inputs avoid one array); structured + random sets, then coordinate descent, stay within
+    the probe budget and end on a fast set; the report names it."""
+    from mi_fieldcalc_amd.placement import choose_search
+
+    made = []
+
+    def allocate():
+        made.append(len(made))
+        return made[-1]
+
+    calls = [0]
+
+    def probe(arrays):
+        calls[0] += 1
+        u, v, r, d = arrays
+        t = 0.435
+        if (r + d) % 5 == 0:
+            t -= 0.02
+        if u % 3 != 0 and v % 3 != 0:
+            t -= 0.015
+        return t
+
+    chosen, report = choose_search(allocate, 4, probe, pool_size=16, random_sets=8, max_probes=80)
+    assert len(made) == 16 and len(set(chosen)) == 4
+    assert report["probes"] <= 80 and calls[0] == report["probes"] + 1  # + the confirming probe
+    assert abs(report["chosen_ms"] - 0.40) < 1e-9 and report["chosen"] == list(chosen)
+    assert report["allocated_in_one_go_ms"] == round(probe((0, 1, 2, 3)), 4)
+    with pytest.raises(ValueError):
+        choose_search(allocate, 4, probe, pool_size=3)
