@@ -27,20 +27,46 @@ def main():
     ctx.use_torch_stream()
     al, bl = synth.hybrid_levels(max(NLEV, 3))
     al, bl = al[:NLEV], bl[:NLEV]
+    # SPREAD_GIB=<g>: every array of the two buffer sets is allocated behind a spacer of g GiB, so that the arrays a launch
+    # streams do not lie next to each other in physical memory (arrays allocated one after the other are the slow
+    # placement: mi-fieldcalc_amd/placement.py); unset = allocations as they come
+    spread = float(os.environ.get("SPREAD_GIB", "0"))
+    spacers = []
+
+    def fresh():
+        if spread > 0:
+            spacers.append(torch.empty(int(spread * 2**30), dtype=torch.uint8, device=dev))
+        return torch.empty((NLEV, NY, NX), dtype=torch.float32, device=dev)
+
     sets = []
     for s in range(2):
+        dst = {k: fresh() for k in ("u", "ff", "t", "temp", "v", "hum", "q", "hum2", "dd")}
         u, v = synth.device_wind(NX, NY, NLEV, 100 + s, dev)
         t, q, ps = synth.device_thermo(NX, NY, NLEV, 200 + s, dev)
-        sets.append(dict(u=u, v=v, t=t, q=q, ps=ps, out={k: torch.empty_like(u) for k in ("ff", "temp", "hum", "hum2", "dd")}))
+        for k, src in (("u", u), ("v", v), ("t", t), ("q", q)):
+            dst[k].copy_(src)
+        del u, v, t, q
+        torch.cuda.empty_cache()
+        sets.append(dict(u=dst["u"], v=dst["v"], t=dst["t"], q=dst["q"], ps=ps, out={k: dst[k] for k in ("ff", "temp", "hum", "hum2", "dd")}))
+    if spread > 0:
+        print("arrays allocated behind spacers of %.1f GiB" % spread)
     cnt = torch.zeros(5 * NLEV, dtype=torch.int64, device=dev)
     n = NX * NY * NLEV
     print("%dx%dx%d, kernel ms by HIP events (median of 9), two rotating buffer sets" % (NX, NY, NLEV))
     print("%-34s %-14s %8s %9s %7s" % ("outputs", "flags / blocks", "ms", "GB/s", "frac"))
     for blocks in os.environ.get("DERIVED_SWEEP", ",4096,8192,16384,32768,65536,140000").split(","):
+        pipe = None
+        if blocks.startswith("pipe"):  # "pipe0" / "pipe1": the default grid with / without the two-trip software pipeline
+            pipe, blocks = blocks[4:], ""
         if blocks:
             os.environ["MIFC_DERIVED_BLOCKS"] = blocks
         else:
             os.environ.pop("MIFC_DERIVED_BLOCKS", None)
+        if pipe is None:
+            os.environ.pop("MIFC_DERIVED_PIPE", None)
+        else:
+            os.environ["MIFC_DERIVED_PIPE"] = pipe
+            blocks = "pipe" + pipe
         ctx.reload_env()
         if os.environ.get("DERIVED_ONLY_TRIO"):
             pass

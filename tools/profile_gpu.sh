@@ -8,11 +8,12 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-# The default command with MANY timed steps: rocprof averages over ALL dispatches of the kernel, i.e. also over
-# the ~300 probe launches of the placement step (other arrays, 0-4 % slower); with 1000 timed launches on the
-# chosen arrays the average is theirs to 1 %.
+# The default command with MANY timed steps: --stats averages over ALL dispatches of the kernel, i.e. also over
+# the ~2 600 probe launches of the placement search (other arrays, 0-12 % slower); tools/summarize_prof.py therefore
+# also averages the LAST dispatches of the kernel trace (the timed region + the per-launch pairs, all on the chosen
+# batch).  The counter passes skip the search: the bytes a launch moves do not depend on where the arrays lie.
 CMD="python3 bench.py --steps 1000 --warmup 5 --no-cpu-baseline --no-verify --no-check-variant"
-PMC_CMD="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-verify --no-check-variant"
+PMC_CMD="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-verify --no-check-variant --placement-pool 0"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"

@@ -33,6 +33,30 @@ def main():
             name = r.get("Name", "")[:90]
             print("  %-90s calls=%s avg_ns=%s min_ns=%s max_ns=%s pct=%s" % (
                 name, r.get("Calls"), r.get("AverageNs"), r.get("MinNs"), r.get("MaxNs"), r.get("Percentage")))
+    # ---- the dispatches of the timed region only: bench.py's placement search launches the kernel a few thousand
+    # times on OTHER arrays before it settles on a batch, and --stats averages over all of them; the timed steps
+    # (and the per-launch event pairs behind them) are the last dispatches of the process
+    steps = None
+    tlog = os.path.join(root, "trace.log")
+    if os.path.exists(tlog):
+        for line in open(tlog):
+            if line.startswith("{") and '"steps"' in line:
+                try:
+                    steps = int(json.loads(line)["steps"])
+                except (ValueError, KeyError):
+                    pass
+    for f in find(os.path.join(root, "trace"), "*kernel_trace.csv"):
+        with open(f) as fh:
+            rows = [r for r in csv.DictReader(fh) if kernel in r.get("Kernel_Name", "")]
+        if not rows:
+            continue
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+        print("== kernel trace: %d dispatches of %s in the process, average %.0f ns over all of them" % (len(dur), kernel, sum(dur) / len(dur)))
+        if steps:
+            last = dur[-2 * steps:] if len(dur) >= 2 * steps else dur[-steps:]
+            print("   the last %d dispatches (the timed region of %d steps + the per-launch event pairs, all on the chosen batch): average %.0f ns, min %d, max %d"
+                  % (len(last), steps, sum(last) / len(last), min(last), max(last)))
     # ---- what bench.py itself measured (HIP events) inside the traced process, for comparison
     tlog = os.path.join(root, "trace.log")
     if os.path.exists(tlog):
