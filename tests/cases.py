@@ -107,15 +107,29 @@ def fused2_cases():
             xn[j, i] = np.float32(0.0)
             variants.append(("nan-gradient-some", zn, SOME_DEFINED, xn))
             variants.append(("nan-gradient-all", zn, ALL_DEFINED, xn))
-        for name, z_, flag, xm_ in variants:
+        if ny >= 7:
+            # map factors below 2^-125 in two rows (subnormal, odd mantissas: 0.5 * m is not exact) next to ordinary rows,
+            # with a field large enough there that the products are ordinary numbers again: the one-launch kernels halve
+            # a row of map factors once when they can and must take the generic products for these rows and for the
+            # iterations that mix them with halved rows
+            zt, xt, yt = z.copy(), xm.copy(), ym.copy()
+            j = ny // 2
+            tiny = np.float32(2.0) ** np.float32(-110)
+            xt[j:j + 2] = (xt[j:j + 2] * tiny).astype(np.float32)
+            yt[j + 1:j + 2] = (yt[j + 1:j + 2] * tiny).astype(np.float32)
+            zt[j - 1:j + 3] = (zt[j - 1:j + 3] * np.float32(2.0) ** np.float32(60)).astype(np.float32)
+            variants.append(("tiny-maps-all", zt, ALL_DEFINED, xt, yt))
+            variants.append(("tiny-maps-some", zt, SOME_DEFINED, xt, yt))
+        for name, z_, flag, xm_, *rest in variants:
+            ym_ = rest[0] if rest else ym
             base = dict(nx=nx, ny=ny, fdefined=flag, undef=UNDEF)
             lab = "%dx%d-%s" % (nx, ny, name)
-            out.append(dict(base, op="thermalFrontParameter", args=[z_, xm_, ym], label="tfp-" + lab))
+            out.append(dict(base, op="thermalFrontParameter", args=[z_, xm_, ym_], label="tfp-" + lab))
             bad = (z_ == UNDEF) | np.isnan(z_)
             with np.errstate(all="ignore"):
                 tq = np.where(bad, z_, np.float32(250.0) + np.float32(0.05) * (z_ - np.float32(5500.0))).astype(np.float32)
             for c in (1, 2, 3, 4):
-                out.append(dict(base, op="plevelqvector", args=[z_, tq, xm_, ym, fc, 700.0, c], label="qvector%d-%s" % (c, lab)))
+                out.append(dict(base, op="plevelqvector", args=[z_, tq, xm_, ym_, fc, 700.0, c], label="qvector%d-%s" % (c, lab)))
     return out
 
 
