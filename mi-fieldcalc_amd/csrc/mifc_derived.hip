@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
   // the loads of the first trip go out before the lookup tables (4.9 KiB) are staged in LDS
   Trip cur = load(q < n4 ? q : 0u);
   if (need_ewt)
-    ewt_table_init(s_ewt);
+    ewt_table_init(s_ewt, !need_pow); // one barrier for both tables
   if (need_pow)
     PT = kappa_tables_init(s_pow);
   if (!PIPE) {

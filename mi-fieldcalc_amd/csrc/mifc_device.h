@@ -50,26 +50,18 @@ struct EwtTable
   const float* tab; // LDS
 };
 
-__device__ __forceinline__ void ewt_table_init(float* lds_tab)
+#include "mifc_ewt_image.h"
+// Stages the table image (tools/gen_ewt_image.py: the 41 values, the start indices of the inverse lookup and the
+// reciprocals of the bin widths, 600 bytes) in LDS: a plain copy, one dword per lane.  `sync = false` leaves the
+// barrier to a second staging call that follows (one barrier for both tables).
+__device__ __forceinline__ void ewt_table_init(float* lds_tab, bool sync = true)
 {
-  // values are the reference's double literals rounded to float (MetConstants.h:57-59)
-  const float init[MIFC_N_EWT] = {
-      (float).000034, (float).000089, (float).000220, (float).000517, (float).001155, (float).002472, (float).005080, (float).01005, (float).01921,
-      (float).03553,  (float).06356,  (float).1111,   (float).1891,   (float).3139,   (float).5088,   (float).8070,   (float)1.2540, (float)1.9118,
-      (float)2.8627,  (float)4.2148,  (float)6.1078,  (float)8.7192,  (float)12.272,  (float)17.044,  (float)23.373,  (float)31.671, (float)42.430,
-      (float)56.236,  (float)73.777,  (float)95.855,  (float)123.40,  (float)157.46,  (float)199.26,  (float)250.16,  (float)311.69, (float)385.56,
-      (float)473.67,  (float)578.09,  (float)701.13,  (float)845.28,  (float)1013.25};
-  // first[b]: largest k with ewt[k] <= 2^(b-15) (0 if none), b = 0..25; consecutive entries differ by at most 4
-  const int first[MIFC_EWT_FIRST_N] = {0, 0, 1, 2, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 13, 15, 17, 18, 20, 22, 25, 27, 30, 33, 36, 40};
-  for (int k = threadIdx.x; k < MIFC_N_EWT; k += blockDim.x)
-    lds_tab[k] = init[k];
-  for (int k = threadIdx.x; k < MIFC_EWT_FIRST_N; k += blockDim.x)
-    lds_tab[MIFC_N_EWT + k] = __int_as_float(first[k]);
-  // reciprocals of the bin widths, for the division of the inverse lookup (see Ewt::inverse)
-  double* rcp = reinterpret_cast<double*>(lds_tab + MIFC_EWT_RCP_AT);
-  for (int k = threadIdx.x; k < MIFC_N_EWT; k += blockDim.x)
-    rcp[k] = k + 1 < MIFC_N_EWT ? 1.0 / (double)(init[k + 1] - init[k]) : 0.0;
-  __syncthreads();
+  static_assert(MIFC_EWT_IMAGE_WORDS == MIFC_EWT_LDS, "table image and LDS layout must agree");
+  unsigned int* dst = reinterpret_cast<unsigned int*>(lds_tab);
+  for (int k = threadIdx.x; k < MIFC_EWT_IMAGE_WORDS; k += blockDim.x)
+    dst[k] = mifc_ewt_image[k];
+  if (sync)
+    __syncthreads();
 }
 
 struct Ewt

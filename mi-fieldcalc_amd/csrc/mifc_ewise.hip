@@ -176,10 +176,11 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
   // the lookup tables cost a few hundred cycles per workgroup: staged only
   // for the operator variants that read them (wave-uniform conditions)
   constexpr bool TABLE_FREE = (OP == EW_TEMP_SCALAR || OP == EW_VECTORABS || OP == EW_MOMENTUM_X || OP == EW_MOMENTUM_Y);
+  const bool with_pow = USES_POW && ewise_needs_pow(P);
   if (!TABLE_FREE && ewise_needs_ewt(P))
-    ewt_table_init(s_ewt);
+    ewt_table_init(s_ewt, !with_pow); // one barrier for both tables
   PowTables PT = {nullptr, nullptr, s_pow, s_pow};
-  if (USES_POW && ewise_needs_pow(P))
+  if (with_pow)
     PT = kappa_tables_init(s_pow);
 
   const bool use1 = P.in1 != nullptr;
@@ -265,8 +266,14 @@ hipError_t launch_ewise_op(const EwiseParams& prm, hipStream_t stream)
     // streaming shape that measured fastest on MI355X).  Variants that stage
     // lookup tables per workgroup amortise that over a grid-stride loop
     // (MIFC_EWISE_MAX_BLOCKS overrides the cap, for A/B measurements).
+    // Measured on 1440x720x137 (profiles/r02/experiments/ewise_grid_caps.txt), with the tables staged by a plain copy:
+    // 65 536 workgroups (two or three trips each) run the table variants 10-17 % faster than 4 096 (hleveltemp
+    // 0.343 -> 0.295 ms, hlevelhum 0.475 -> 0.397) and than one trip each; the variants that stage BOTH tables
+    // (humidity from potential temperature) are the exception -- their time grows with the number of workgroups
+    // (0.51 ms at 4 096, 2.3 ms at 65 536) -- and keep the small grid.
     const bool tables = ewise_needs_ewt(prm) || ewise_needs_pow(prm);
-    int cap = tables ? 256 * 16 : 0x7fffffff;
+    const bool both = ewise_needs_ewt(prm) && ewise_needs_pow(prm);
+    int cap = both ? 256 * 16 : (tables ? 256 * 256 : 0x7fffffff);
     if (env().ewise_max_blocks > 0)
       cap = env().ewise_max_blocks;
     hipLaunchKernelGGL((ewise_kernel<OP, true>), dim3(grid_for(n4, block, cap)), dim3(block), 0, stream, prm);

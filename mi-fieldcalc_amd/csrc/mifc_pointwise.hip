@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
     if (q < n4)
       fetch(q);
     if (PwTraits<OP>::ewt)
-      ewt_table_init(s_ewt);
+      ewt_table_init(s_ewt, PwTraits<OP>::pow == 0); // one barrier for both tables
     if (PwTraits<OP>::pow == 1)
       PT = pow_tables_init(s_pow);
     if (PwTraits<OP>::pow == 2)
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
     }
   } else {
     if (PwTraits<OP>::ewt)
-      ewt_table_init(s_ewt);
+      ewt_table_init(s_ewt, PwTraits<OP>::pow == 0); // one barrier for both tables
     if (PwTraits<OP>::pow == 1)
       PT = pow_tables_init(s_pow);
     if (PwTraits<OP>::pow == 2)

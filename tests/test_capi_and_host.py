@@ -417,3 +417,29 @@ def test_choose_search_finds_the_fast_combination():
     assert report["allocated_in_one_go_ms"] == round(probe((0, 1, 2, 3)), 4)
     with pytest.raises(ValueError):
         choose_search(allocate, 4, probe, pool_size=3)
+
+
+def test_saturation_table_image_is_current():
+    """csrc/mifc_ewt_image.h (the LDS image the kernels copy per workgroup) is what tools/gen_ewt_image.py generates
+    from the reference's table (MetConstants.h:57-59), and its reciprocals are those of the FLOAT bin widths."""
+    import struct
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_ewt_image.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_ewt_image as g
+
+    words, first = g.image()
+    tab = np.array(words[:41], dtype=np.uint32).view(np.float32)
+    assert tab[0] == np.float32(.000034) and tab[40] == np.float32(1013.25)
+    rcp = np.array(words[68:], dtype=np.uint32).view(np.float64)
+    assert len(rcp) == 41 and rcp[40] == 0.0
+    assert all(rcp[k] == 1.0 / np.float64(tab[k + 1] - tab[k]) for k in range(40))
+    # first[b]: the walk of MetConstants.cc:37-45 from the top of the table stops there for et = 2^(b-15)
+    for b, k in enumerate(first):
+        et = np.float32(2.0) ** np.float32(b - 15)
+        ll = 40
+        while ll > 0 and tab[ll] > et:
+            ll -= 1
+        assert ll == k
