@@ -1,0 +1,19 @@
+#!/bin/bash
+# Clocks / power / temperatures of the box WHILE the headline kernel runs (rocm-smi sampled once a second next to a
+# long bench.py run), to see what distinguishes the boxes on which the same binary runs at 66 % and at 73.5 % of 8 TB/s.
+#   bash tools/box_state.sh > gpurun_out/box_state_under_load.txt
+python3 bench.py --steps 25000 --warmup 5 --no-cpu-baseline --no-verify --no-check-variant > /tmp/box_bench.json 2>/dev/null &
+BP=$!
+sleep 6
+for i in 1 2 3 4; do
+  rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -E "fclk|mclk|sclk|socclk|Power \(W\)|Temperature"
+  echo "--"
+  sleep 1
+done
+wait $BP
+python3 -c "
+import json
+d=json.loads(open('/tmp/box_bench.json').readline())
+print('bench: kernel_ms_avg', d['roofline']['kernel_ms_avg'], 'frac', d['roofline']['frac'], 'placement', d['config']['placement']['probe_ms_min_median_max'])
+"
+rocm-smi --showuniqueid 2>/dev/null | grep -i unique
