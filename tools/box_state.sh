@@ -17,3 +17,9 @@ d=json.loads(open('/tmp/box_bench.json').readline())
 print('bench: kernel_ms_avg', d['roofline']['kernel_ms_avg'], 'frac', d['roofline']['frac'], 'placement', d['config']['placement']['probe_ms_min_median_max'])
 "
 rocm-smi --showuniqueid 2>/dev/null | grep -i unique
+rocm-smi --showmemorypartition --showcomputepartition 2>/dev/null | grep -iE "partition"
+rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock Freq|Wavefront|Cacheline|L2:|L3:|Memory Properties|Size:" | sort | uniq -c | head -30
+rocm-smi --showrasinfo all 2>/dev/null | grep -iE "UMC|HBM|correct" | head -10
+cat /sys/class/drm/card*/device/mem_info_vram_vendor 2>/dev/null | head -2
+cat /sys/class/drm/card*/device/vbios_version 2>/dev/null | head -2
+cat /sys/module/amdgpu/version 2>/dev/null

@@ -9,7 +9,7 @@ D=gpurun_out/prof_derived_${TAG}
 O=profiles/${TAG}
 mkdir -p "$O"
 cp "$E"/bench_n1.json "$E"/bench_repeat.txt "$E"/bench_derived.txt "$E"/bench_f1_levels.txt "$E"/per_operator_table.txt "$E"/hostpath.jsonl \
-   "$E"/other_configs.jsonl "$E"/multigpu_gloo_rehearsal.jsonl "$E"/sweep_same_device_as_bench.txt "$O"/
+   "$E"/other_configs.jsonl "$E"/multigpu_gloo_rehearsal.jsonl "$E"/sweep_same_device_as_bench.txt "$E"/box.txt "$O"/
 newest() { ls -t "$@" 2>/dev/null | head -1; }
 cp "$(newest "$P"/trace/*/*kernel_stats.csv)" "$O"/kernel_stats.csv
 cp "$P"/summary.txt "$O"/rocprofv3_summary.txt

@@ -6,6 +6,9 @@ TAG=${1:-r02}
 O=gpurun_out/${TAG}_end
 mkdir -p "$O"
 export TMPDIR=/tmp
+# which box: the same binary runs the headline kernel at 66 % on some boxes of the pool and at 73.5 % on others
+{ rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id"; echo "HBM vendor: $(cat /sys/class/drm/card*/device/mem_info_vram_vendor 2>/dev/null | head -1)"; echo "vbios: $(cat /sys/class/drm/card*/device/vbios_version 2>/dev/null | head -1)"; } > "$O/box.txt" 2>&1
+cat "$O/box.txt"
 python3 bench.py --steps 20 --warmup 5 > "$O/bench_n1.json" 2> "$O/bench_n1.err"
 echo "bench rc=$?"; cat "$O/bench_n1.json"
 echo "# five consecutive processes of 'python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline' on ONE box, same binary" > "$O/bench_repeat.txt"
