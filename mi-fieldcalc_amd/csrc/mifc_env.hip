@@ -50,6 +50,7 @@ void env_reload()
   e.derived_blocks = positive_int("MIFC_DERIVED_BLOCKS");
   e.derived_pipe = not_zero("MIFC_DERIVED_PIPE") ? 1 : 0;
   e.levelwalk = not_zero("MIFC_VORTDIV_LEVELWALK");
+  e.split_roles = not_zero("MIFC_VORTDIV_SPLIT");
   e.levelwalk_min_units = positive_int("MIFC_LEVELWALK_MIN_UNITS");
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     e.has_vortdiv_tune = true;

@@ -995,6 +995,219 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
 chunk_done:;
 }
 
+// ---------------------------------------------------------------------------
+// Split-role level-walking form (tuning K=4): the tile, the walk through a chunk of levels and the arithmetic of the
+// level-walking kernel above, but the waves of a workgroup either LOAD or COMPUTE AND STORE, never both:
+//   * NL loader waves bring the TR + 2 rows of u and of v of a level (and the 2 x 2 edge scalars of every row)
+//     straight from global memory into LDS (global_load_lds_dwordx4: no registers, no ds_write), PF levels ahead of the
+//     level being computed, into a ring of PF + 1 level buffers;
+//   * TR compute waves (one row each) take everything from LDS -- own row, the rows above and below, the edge
+//     scalars -- x-neighbours from the adjacent lanes, and store 2 x 1 KiB; the only thing in their vmcnt queue is
+//     stores, which nothing in the loop ever waits for.
+// Why: on gfx9 a wave's loads and stores share ONE in-order counter, so a wave that loads for level l + 1 after it
+// stored level l - 1 gets its data "back" only when those older stores have been acknowledged.  The copy yardsticks
+// show what that coupling costs (one process, 2 x 1.136 GB each way): loop copy 0.42-0.45 ms, the same loop with
+// split roles 0.364-0.371, one-shot 0.367, one-shot with split roles 0.339.
+//   iteration for level lev (t = lev - lev0), ONE barrier:
+//       loaders:  s_waitcnt vmcnt((PF - 1) * L)      level lev has landed in buffer t % (PF + 1)
+//       everyone: s_barrier
+//       loaders:  issue level lev + PF into buffer (t + PF) % (PF + 1)   -- the buffer of level lev - 1, whose readers
+//                                                                           all passed the barrier above
+//       computes: level lev from buffer t % (PF + 1)
+// A loader wave issues the same number L of load instructions for every level (a wave with fewer rows repeats its last
+// one), so that the wait count is an immediate; loader 0, which also gathers the edge scalars, has its own copy of the loop.
+template <bool CHECK, bool NT, int TR, int NL, int PF>
+__global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const RowsParams P)
+{
+  constexpr int NB = PF + 1;                // level buffers
+  constexpr int NS = TR + 2;                // row slots per level: slot s holds tile row s - 1
+  constexpr int KMAX = (NS + NL - 1) / NL;  // row slots per loader wave
+  static_assert(4 * NS <= 64, "the edge scalars of a level are one dword per lane");
+  __shared__ v4f srow[NB][NS][2][64];       // [buffer][slot][u | v][lane]
+  __shared__ float sedge[NB][64];           // [buffer][4 * slot + 2 * (u | v) + (west | east)]
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int bid = blockIdx.x;
+  const int seq = P.xcd_remap ? ((bid & 7) * P.per_xcd + (bid >> 3)) : bid;
+  if (seq >= P.n_logical)
+    return;
+  const int ntiles = P.uB * P.uW;
+  const int lchunk = seq / ntiles;
+  const int tile = seq - lchunk * ntiles;
+  const int rblock = tile / P.uW;
+  const int wc = tile - rblock * P.uW;
+  const int lev0 = lchunk * P.lgroup;
+  const int lev1 = (lev0 + P.lgroup < P.nlev) ? lev0 + P.lgroup : P.nlev;
+  const int nx = P.nx;
+  const int first = P.lo + rblock * TR; // first row of the tile (always computed)
+  const int col = wc * 256 + lane * 4;
+  const bool act = col < nx;
+  const int col_c = act ? col : nx - 4;
+  int east_col = wc * 256 + 256;
+  if (east_col > nx)
+    east_col = nx;
+
+  if (wave >= TR) {
+    // ------------------------------------------------------------------ loader
+    const int lw = wave - TR;
+    int off[KMAX], slot_of[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int s = lw + NL * k;
+      if (s > NS - 1)
+        s = NS - 1; // a wave with fewer rows repeats the last slot (same data to the same place)
+      const int jl_raw = first + s - 1;
+      const int jl = jl_raw < P.hi ? jl_raw : P.hi; // rows past the computed range: row `hi` always exists
+      slot_of[k] = s;
+      off[k] = jl * nx + col_c;
+    }
+    // edge scalars: lane i gathers (slot i / 4, array (i / 2) % 2, side i % 2); lanes past 4 NS repeat lane 0's
+    const int ei = (lane < 4 * NS) ? lane : 0;
+    const int es = ei >> 2;
+    const bool e_is_v = ((ei >> 1) & 1) != 0;
+    const int ejl_raw = first + es - 1;
+    const int ejl = ejl_raw < P.hi ? ejl_raw : P.hi;
+    long e64 = (long)ejl * nx + ((ei & 1) ? east_col : (wc * 256 - 1));
+    e64 = e64 < P.idx_lo ? P.idx_lo : (e64 > P.idx_hi ? P.idx_hi : e64);
+    const int eoff = (int)e64;
+    const float* __restrict__ ebase = e_is_v ? P.v : P.u;
+
+    // loader 0 also gathers the edge scalars of the level (one dword per lane); the wait count is an immediate, so the
+    // two kinds of loader run their own copy of the loop
+    auto walk = [&](auto edge_tag) __attribute__((always_inline)) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
+      constexpr int L = 2 * KMAX + (EDGE ? 1 : 0); // load instructions per level of this wave
+      auto issue = [&](int lev, int b) {
+        const int l = lev < lev1 ? lev : lev1 - 1; // past the chunk: a valid address into a buffer nobody reads
+        const float* __restrict__ u = P.u + (size_t)l * P.in_stride;
+        const float* __restrict__ v = P.v + (size_t)l * P.in_stride;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(u + off[k]),
+                                           (void __attribute__((address_space(3)))*)&srow[b][slot_of[k]][0][0], 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(v + off[k]),
+                                           (void __attribute__((address_space(3)))*)&srow[b][slot_of[k]][1][0], 16, 0, 0);
+        }
+        if (EDGE)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(ebase + (size_t)l * P.in_stride + eoff),
+                                           (void __attribute__((address_space(3)))*)&sedge[b][0], 4, 0, 0);
+      };
+#pragma unroll
+      for (int k = 0; k < PF; ++k)
+        issue(lev0 + k, k);
+      int b_next = PF % NB; // buffer of level lev + PF
+      for (int lev = lev0; lev < lev1; ++lev) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PF - 1) * L) : "memory");
+        issue(lev + PF, b_next);
+        b_next = (b_next + 1 == NB) ? 0 : b_next + 1;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land in LDS after the workgroup has gone
+    };
+    if (lw == 0)
+      walk(std::true_type());
+    else
+      walk(std::false_type());
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute
+  const int slot = wave + 1;
+  const int jl_raw = first + wave;
+  const bool computes = jl_raw < P.hi;
+  const int jl = computes ? jl_raw : P.hi;
+  const int j = P.j0 + jl;
+  const float undef = P.undef;
+  const int base = jl * nx;
+  const int o = base + col_c;
+  const bool top = (j == 1) && (P.j0 == 0);
+  const bool bottom = (j == P.nyg - 2) && (P.j0 + P.ny_local == P.nyg);
+  const bool last_in_seg = col + 4 >= east_col;
+  const int oo = base + col;
+  v4f xm4 = {0.f, 0.f, 0.f, 0.f}, ym4 = xm4;
+  if (computes) { // the tile's map factors: once, for every level of the chunk
+    xm4 = load4(P.xm + o);
+    ym4 = load4(P.ym + o);
+  }
+  int buf = 0;
+  for (int lev = lev0; lev < lev1; ++lev) {
+    // the LDS reads of the previous level are consumed (their values went into the stores); stores stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (computes) {
+      const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
+      const v4f uc = srow[buf][slot][0][lane], vc = srow[buf][slot][1][lane];
+      const float uWe = sedge[buf][4 * slot + 0], uEe = sedge[buf][4 * slot + 1];
+      const float vWe = sedge[buf][4 * slot + 2], vEe = sedge[buf][4 * slot + 3];
+      const float uW = dpp_from_lower_lane(uWe, uc.w), vW = dpp_from_lower_lane(vWe, vc.w); // lane 0 keeps the west scalar
+      float uE = dpp_from_upper_lane(uEe, uc.x), vE = dpp_from_upper_lane(vEe, vc.x);       // lane 63 keeps the east scalar
+      if (last_in_seg) {
+        uE = uEe;
+        vE = vEe;
+      }
+      bool ok[4] = {true, true, true, true};
+      unsigned int bad = 0;
+      {
+        const v4f un = srow[buf][slot + 1][0][lane], us = srow[buf][slot - 1][0][lane];
+        const float vcx[6] = {vW, vc.x, vc.y, vc.z, vc.w, vE};
+        float zv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float vw = vcx[k], ve = vcx[k + 2];
+          if (CHECK) // both operators test these four values (:1861, :1927)
+            ok[k] = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef));
+          zv[k] = ok[k] ? f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]) : undef;
+          if (CHECK && !ok[k] && act)
+            bad += 1;
+        }
+        if (col == 0) // fillEdges, column part (:65-68)
+          zv[0] = zv[1];
+        if (col + 4 == nx)
+          zv[3] = zv[2];
+        if (act) {
+          float* rv = P.rv + (size_t)lev * P.out_stride;
+          v4f z4;
+          z4.x = zv[0];
+          z4.y = zv[1];
+          z4.z = zv[2];
+          z4.w = zv[3];
+          store4<NT>(rv + oo, z4);
+          if (top) // fillEdges, row part (:70-73)
+            store4<NT>(rv + oo - nx, z4);
+          if (bottom)
+            store4<NT>(rv + oo + nx, z4);
+        }
+      }
+      {
+        const v4f vn = srow[buf][slot + 1][1][lane], vs = srow[buf][slot - 1][1][lane];
+        const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
+        float zd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          zd[k] = ok[k] ? f_diverg(xm4[k], ym4[k], ucx[k + 2] - ucx[k], vn[k] - vs[k]) : undef;
+        if (col == 0)
+          zd[0] = zd[1];
+        if (col + 4 == nx)
+          zd[3] = zd[2];
+        if (act) {
+          float* dv = P.dv + (size_t)lev * P.out_stride;
+          v4f d4;
+          d4.x = zd[0];
+          d4.y = zd[1];
+          d4.z = zd[2];
+          d4.w = zd[3];
+          store4<NT>(dv + oo, d4);
+          if (top)
+            store4<NT>(dv + oo - nx, d4);
+          if (bottom)
+            store4<NT>(dv + oo + nx, d4);
+        }
+      }
+      if (CHECK && P.n_undefined && !all)
+        wave_count_add(P.n_undefined + lev, bad);
+    }
+    buf = (buf + 1 == NB) ? 0 : buf + 1;
+  }
+}
+
 struct Tuning
 {
   int K;     // 0: row-walking kernel (default), 1: one-shot kernel, 2: one-shot tiles with the row reuse in LDS, 3: level-walking tiles
@@ -1218,6 +1431,15 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         t.ZZ = 1;
         t.D = 0;
         t.LG = (prm.nlev + nchunks - 1) / nchunks;
+        // The fused pair: the same tiles with split roles -- 2 loader waves bring 14 rows of u and v straight into LDS
+        // two levels ahead, 12 compute waves only read LDS and store (vortdiv_split_kernel).  1-5 % faster than the
+        // form above on every box, placement and shape tried, 4 % on the tested variant, up to 18 % on shallow batches
+        // (profiles/r02/experiments/sweep_k4_*.txt, ab_split_roles.txt).
+        if (rv && dv && env().split_roles) {
+          t.K = 4;
+          t.D = 1;
+          t.WPB = 2;
+        }
       }
     }
     while (t.R > 2 && waves_per_band * ((rows + t.R - 1) / t.R) < 2048)
@@ -1418,6 +1640,44 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         LEVELWALK(8, 1);
       }
 #undef LEVELWALK
+      return hipGetLastError();
+    }
+  }
+  if (t.K == 4 && !rp.fc && prm.op != ST_JACOBIAN && rv && dv) { // split-role level-walking tiles (loader waves / compute waves)
+    const int tile_rows = (t.RB == 6 || t.RB == 8 || t.RB == 12 || t.RB == 14) ? t.RB : 10;
+    rp.uB = (rp.hi - rp.lo + tile_rows - 1) / tile_rows;
+    rp.uW = (nx + 255) / 256;
+    rp.lgroup = (t.LG > 0 && t.LG < prm.nlev) ? t.LG : prm.nlev; // levels per workgroup
+    const int nchunks = (prm.nlev + rp.lgroup - 1) / rp.lgroup;
+    const long units = (long)nchunks * rp.uB * rp.uW;
+    if (units <= 0x3fffffffL && (long)nx * (rp.ny_local + 2) < 0x7fffffffL) {
+      rp.n_logical = (int)units;
+      rp.per_xcd = (rp.n_logical + 7) / 8;
+      grid = rp.per_xcd * 8;
+      const bool chk = !prm.every_level_all_defined;
+      const int pf = t.D >= 2 ? 3 : (t.D == 1 ? 2 : 1); // D selects how many levels the loaders run ahead
+      const int nl = (t.WPB == 2 || t.WPB == 4) ? t.WPB : (tile_rows == 10 ? 4 : 2); // WPB doubles as the number of loader waves
+#define SPLIT(TR_, NL_, PF_)                                                                                                          \
+  if (chk)                                                                                                                            \
+    hipLaunchKernelGGL((vortdiv_split_kernel<true, true, TR_, NL_, PF_>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp);          \
+  else                                                                                                                                \
+    hipLaunchKernelGGL((vortdiv_split_kernel<false, true, TR_, NL_, PF_>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp)
+      if (tile_rows == 6) {
+        if (pf == 3) { SPLIT(6, 2, 3); } else if (pf == 2) { SPLIT(6, 2, 2); } else { SPLIT(6, 2, 1); }
+      } else if (tile_rows == 8) {
+        if (pf == 3) { SPLIT(8, 2, 3); } else if (pf == 2) { SPLIT(8, 2, 2); } else { SPLIT(8, 2, 1); }
+      } else if (tile_rows == 12 && nl == 4) {
+        if (pf >= 2) { SPLIT(12, 4, 2); } else { SPLIT(12, 4, 1); }
+      } else if (tile_rows == 12) {
+        if (pf == 3) { SPLIT(12, 2, 3); } else if (pf == 2) { SPLIT(12, 2, 2); } else { SPLIT(12, 2, 1); }
+      } else if (tile_rows == 14) { // 16 waves: two loaders at most
+        if (pf >= 2) { SPLIT(14, 2, 2); } else { SPLIT(14, 2, 1); }
+      } else if (nl == 2) {
+        if (pf >= 2) { SPLIT(10, 2, 2); } else { SPLIT(10, 2, 1); }
+      } else {
+        if (pf == 3) { SPLIT(10, 4, 3); } else if (pf == 2) { SPLIT(10, 4, 2); } else { SPLIT(10, 4, 1); }
+      }
+#undef SPLIT
       return hipGetLastError();
     }
   }

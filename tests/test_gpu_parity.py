@@ -360,7 +360,9 @@ def _expect_levels(oracle, u, v, xm, ym, flags):
 @pytest.mark.parametrize("tune", ["", "R=7,D=0", "R=5,D=1,NT=1", "R=64,D=1,WPB=8", "K=1", "K=1,XCD=0,NT=0", "K=2", "K=2,XCD=0", "R=1", "R=2,WPB=2", "R=8",
                                   "K=2,LG=8", "K=2,LG=4,XCD=0", "K=1,LG=3", "K=2,RB=14", "K=2,RB=14,LG=16",
                                   "K=3", "K=3,RB=8,LG=2", "K=3,RB=16,LG=4,XCD=0", "K=3,RB=12,LG=1", "K=3,RB=16,LG=3,D=0", "K=3,RB=8,D=0,LG=4",
-                                  "K=3,RB=16,LG=2,D=0,ZZ=1", "K=3,RB=12,D=1,ZZ=1", "K=3,RB=8,LG=5,D=0,ZZ=1,XCD=0"])
+                                  "K=3,RB=16,LG=2,D=0,ZZ=1", "K=3,RB=12,D=1,ZZ=1", "K=3,RB=8,LG=5,D=0,ZZ=1,XCD=0",
+                                  "K=4", "K=4,D=0,LG=1", "K=4,D=1,LG=3", "K=4,D=2,LG=2,XCD=0", "K=4,RB=6,D=2,LG=4", "K=4,RB=8,D=1,LG=5", "K=4,RB=12,D=1,LG=2",
+                                  "K=4,RB=6,D=0"])
 def test_vortdiv_levels_matches_per_level_reference_calls(gpu_ctx, oracle, nx, ny, nlev, tune, mifc_env):
     import torch
 
@@ -465,7 +467,7 @@ def test_vortdiv_enqueue_counts(gpu_ctx, oracle):
 # ------------------------------------------------------------------ row slabs
 @pytest.mark.parametrize("nx,ny,nslab", [(64, 40, 4), (260, 23, 3), (512, 64, 8), (33, 17, 2)])
 @pytest.mark.parametrize("mode", ["all", "some"])
-@pytest.mark.parametrize("tune", [None, "K=2", "R=8"])
+@pytest.mark.parametrize("tune", [None, "K=2", "R=8", "K=4,D=1", "K=4,RB=6,D=2"])
 def test_vortdiv_row_slabs_equal_whole_field(gpu_ctx, oracle, nx, ny, nslab, mode, tune, mifc_env):
     """Config 4 decomposition exercised on one GPU with a loop-back halo 'exchange' (the launcher picks the
     kernel form by launch size: the default, the one-shot tiles and the row-walking form all have to agree)."""
