@@ -23,5 +23,5 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC
   echo "pmc $C rc=$?"
 done
 # compact summaries
-python3 tools/summarize_prof.py "$OUT" vortdiv_levelwalk_kernel > "$OUT/summary.txt" 2>&1
+python3 tools/summarize_prof.py "$OUT" vortdiv_split_kernel > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

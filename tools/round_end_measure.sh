@@ -17,8 +17,9 @@ for i in 1 2 3 4 5; do
   python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'], d.get('check_variant',{}).get('roofline_frac'), d['verified'])" >> "$O/bench_repeat.txt"
 done
 cat "$O/bench_repeat.txt"
-W="K=3,RB=12,LG=6,ZZ=1,D=0"   # what the library picks for this batch
-SWEEP_NO_YARD=1 python3 tools/sweep_vortdiv.py "$W" "$W,XS=1" "$W,XL=1" "$W,XS=1,XL=1" "R=8" "R=8,XS=1" "R=8,XL=1" > "$O/sweep_same_device_as_bench.txt" 2>&1
+W="K=3,RB=12,LG=6,ZZ=1,D=0"   # the level-walking kernel whose waves load and store (MIFC_VORTDIV_SPLIT=0); the measurement knobs exist for it
+W4="K=4,RB=12,LG=6,D=1,WPB=2"  # what the library picks for this batch: the split-role kernel
+SWEEP_NO_YARD=1 python3 tools/sweep_vortdiv.py "$W4" "$W" "$W,XS=1" "$W,XL=1" "$W,XS=1,XL=1" "R=8" "R=8,XS=1" "R=8,XL=1" > "$O/sweep_same_device_as_bench.txt" 2>&1
 echo "sweep rc=$?"
 bash tools/profile_gpu.sh "$TAG" > "$O/profile_gpu.log" 2>&1
 echo "profile rc=$?"; tail -25 "$O/profile_gpu.log"
