@@ -89,6 +89,25 @@ bool ensure_levels(mifc_ctx* c, size_t nlev)
   return true;
 }
 
+unsigned int* partials_for(mifc_ctx* c, size_t n_cells, int* cap)
+{
+  *cap = 0;
+  const size_t blocks = (n_cells / 4 + 255) / 256; // one float4 per lane, 256 lanes
+  if (blocks < 2048)
+    return nullptr;
+  if (blocks > c->partials_cap) {
+    if (c->d_partials)
+      (void)hipFree(c->d_partials);
+    c->d_partials = nullptr;
+    c->partials_cap = 0;
+    if (hipMalloc((void**)&c->d_partials, blocks * sizeof(unsigned int)) != hipSuccess)
+      return nullptr; // the launch then counts with one atomic per workgroup
+    c->partials_cap = blocks;
+  }
+  *cap = (int)c->partials_cap;
+  return c->d_partials;
+}
+
 bool pinned_acquire(mifc_ctx* c)
 {
   if (c->pinned_read_pending) {
@@ -213,8 +232,10 @@ int run_ewise(mifc_ctx* c, mifc::EwiseParams P, const float* in0, const float* i
   if (!counted)
     P.count = 0;
   P.n_undefined = c->d_counts;
-  if (counted)
+  if (counted) {
     MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64), c->stream));
+    P.partials = partials_for(c, n, &P.partials_cap);
+  }
   MIFC_LAUNCH(c, mifc::launch_ewise(P, c->stream));
   if (counted)
     MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -452,6 +473,8 @@ void mifc_destroy(mifc_ctx* c)
     (void)hipFree(c->d_counts);
   if (c->d_ab)
     (void)hipFree(c->d_ab);
+  if (c->d_partials)
+    (void)hipFree(c->d_partials);
   if (c->d_levels)
     (void)hipFree(c->d_levels);
   if (c->h_pinned)

@@ -63,8 +63,10 @@ int run_pointwise(mifc_ctx* c, int nx, int ny, PwCall& pc, float* out, int* fdef
   if (!ok || !ensure_levels(c, 1))
     return 0;
   P.n_undefined = c->d_counts;
-  if (P.count)
+  if (P.count) {
     MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64), c->stream));
+    P.partials = partials_for(c, n, &P.partials_cap);
+  }
   MIFC_LAUNCH(c, mifc::launch_pointwise(P, c->stream));
   if (P.count) {
     if (!pinned_acquire(c))

@@ -30,6 +30,8 @@ struct mifc_ctx
   u64* d_counts = nullptr;          // 5 * cap_lev
   float* d_ab = nullptr;            // 2 * cap_lev (alevel | blevel; per-level scalars of the batched f1 operators)
   int* d_levels = nullptr;          // cap_lev: level lists of the batched two-stage operators (ALL_DEFINED levels first)
+  unsigned int* d_partials = nullptr; // per-workgroup undefined counts of big one-shot launches (grow-only), see mifc_device.h
+  size_t partials_cap = 0;
   void* h_pinned = nullptr;         // pinned mirror: counts (3*cap u64) + flags (2*cap) + ab (2*cap float)
   size_t cap_lev = 0;
   // recorded after every async copy that READS the pinned mirror (enqueue
@@ -97,6 +99,8 @@ inline void enter(mifc_ctx* c)
 
 bool ensure_slot(mifc_ctx* c, int s, size_t bytes);
 bool ensure_levels(mifc_ctx* c, size_t nlev);
+// scratch for the per-workgroup counts of a counted one-shot launch over n cells (nullptr below the size where it pays)
+unsigned int* partials_for(mifc_ctx* c, size_t n_cells, int* cap);
 bool pinned_acquire(mifc_ctx* c);
 bool pinned_release(mifc_ctx* c);
 bool scratch_release(mifc_ctx* c);

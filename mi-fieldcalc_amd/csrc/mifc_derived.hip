@@ -256,16 +256,12 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
   }
   // The saturation table can reject a cell even when the inputs are ALL_DEFINED (:220-224), so the
   // humidity outputs and theta-e are always counted; ff / plain temperature only when tests ran.
-  if (want_ff && CHECK && P.cnt_ff)
-    wave_count_add(P.cnt_ff + lev, bad_ff);
-  if (want_t && (CHECK || tc >= 4) && P.cnt_temp)
-    wave_count_add(P.cnt_temp + lev, bad_t);
-  if (want_h && P.cnt_hum)
-    wave_count_add(P.cnt_hum + lev, bad_h);
-  if (want_d && P.cnt_td)
-    wave_count_add(P.cnt_td + lev, bad_d);
-  if (want_dd && CHECK && P.cnt_dd)
-    wave_count_add(P.cnt_dd + lev, bad_dd);
+  // one atomic per workgroup and output (every workgroup stays on one level)
+  u64* const ctr[5] = {(want_ff && CHECK && P.cnt_ff) ? P.cnt_ff + lev : nullptr, (want_t && (CHECK || tc >= 4) && P.cnt_temp) ? P.cnt_temp + lev : nullptr,
+                       (want_h && P.cnt_hum) ? P.cnt_hum + lev : nullptr, (want_d && P.cnt_td) ? P.cnt_td + lev : nullptr,
+                       (want_dd && CHECK && P.cnt_dd) ? P.cnt_dd + lev : nullptr};
+  const unsigned int cnt[5] = {bad_ff, bad_t, bad_h, bad_d, bad_dd};
+  block_count_add<5>(ctr, cnt);
 }
 
 template <bool CHECK>

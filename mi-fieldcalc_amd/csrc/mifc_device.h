@@ -530,18 +530,70 @@ __device__ __forceinline__ float wind_direction(float u, float v)
   return dd;
 }
 
-// ---- undefined-cell counting: one atomic per wave, none when nothing to add
-__device__ __forceinline__ void wave_count_add(u64* counter, unsigned int my_count)
+// ---- undefined-cell counting
+// Atomics to ONE address are served one after the other (~12 ns each on MI355X: profiles/r02/experiments/undef_density.txt);
+// a masked field, where every wave has something to count, turned the 0.3 ms of a one-shot elementwise kernel into
+// 6.7 ms of queueing behind its 555 000 per-wave atomics.  So: per-lane counts -> wave butterfly -> LDS atomic ->
+// ONE global atomic per WORKGROUP (block_count_add, for kernels in which every wave of the workgroup reaches the call),
+// or one atomic per wave where the waves of a workgroup do not meet again (wave_count_add); nothing at all where
+// there is nothing to count.
+__device__ __forceinline__ unsigned int wave_sum(unsigned int my_count) // total in lane 0 (all lanes, in fact)
 {
-  if (__builtin_amdgcn_ballot_w64(my_count != 0) == 0) // nothing to count in this wave (the usual case): no shuffles, no atomic
-    return;
-  // wave64 butterfly sum
   unsigned int s = my_count;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
     s += __shfl_xor(s, off, 64);
+  return s;
+}
+__device__ __forceinline__ void wave_count_add(u64* counter, unsigned int my_count)
+{
+  if (__builtin_amdgcn_ballot_w64(my_count != 0) == 0) // nothing to count in this wave (the usual case): no shuffles, no atomic
+    return;
+  const unsigned int s = wave_sum(my_count);
   if ((threadIdx.x & 63) == 0 && s != 0)
     atomicAdd(counter, (u64)s);
+}
+// N counters at once; contains barriers: every wave of the workgroup must call it, with the same N counters
+template <int N>
+__device__ __forceinline__ void block_count_add(u64* const (&counter)[N], const unsigned int (&my_count)[N])
+{
+  __shared__ unsigned int s_total[N];
+  if (threadIdx.x < N)
+    s_total[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (counter[k] && __builtin_amdgcn_ballot_w64(my_count[k] != 0) != 0) {
+      const unsigned int s = wave_sum(my_count[k]);
+      if ((threadIdx.x & 63) == 0)
+        atomicAdd(&s_total[k], s);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < N && counter[threadIdx.x] && s_total[threadIdx.x] != 0)
+    atomicAdd(counter[threadIdx.x], (u64)s_total[threadIdx.x]);
+}
+// the workgroup's count into its own slot (always written: the slots are not zeroed beforehand); barriers inside
+__device__ __forceinline__ void block_count_store(unsigned int* slot, unsigned int my_count)
+{
+  __shared__ unsigned int s_total1;
+  if (threadIdx.x == 0)
+    s_total1 = 0;
+  __syncthreads();
+  if (__builtin_amdgcn_ballot_w64(my_count != 0) != 0) {
+    const unsigned int s = wave_sum(my_count);
+    if ((threadIdx.x & 63) == 0)
+      atomicAdd(&s_total1, s);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    *slot = s_total1;
+}
+__device__ __forceinline__ void block_count_add(u64* counter, unsigned int my_count)
+{
+  u64* const c[1] = {counter};
+  const unsigned int n[1] = {my_count};
+  block_count_add<1>(c, n);
 }
 
 } // namespace mifc

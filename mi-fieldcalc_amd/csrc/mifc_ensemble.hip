@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void ensemble_kernel(const EnsembleParams P)
       P.out[i] = o;
     }
   }
-  wave_count_add(P.n_undefined, bad);
+  block_count_add(P.n_undefined, bad); // one atomic per workgroup
 }
 
 template <int OP>

@@ -234,8 +234,10 @@ __global__ __launch_bounds__(256) void ewise_kernel(const EwiseParams P)
       }
     }
   }
-  if (P.count)
-    wave_count_add(P.n_undefined, bad);
+  if (P.count && P.partials)
+    block_count_store(P.partials + blockIdx.x, bad); // big launch: added up by count_partials_kernel behind it
+  else
+    block_count_add(P.count ? P.n_undefined : nullptr, bad); // one atomic per workgroup
 }
 
 inline bool aligned16(const void* p)
@@ -254,6 +256,28 @@ inline int grid_for(int work_items, int block, int max_blocks)
 } // namespace
 
 namespace {
+// A few workgroups add up the per-workgroup counts of a big launch and hand their sums to the counter (at most 64 atomics).
+__global__ __launch_bounds__(256) void count_partials_kernel(const unsigned int* __restrict__ partials, int n, u64* counter)
+{
+  unsigned int s = 0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    s += partials[i];
+  block_count_add(counter, s);
+}
+} // namespace
+
+hipError_t launch_count_partials(const unsigned int* partials, int n, u64* counter, hipStream_t stream)
+{
+  int g = (n + 2047) / 2048;
+  g = g < 1 ? 1 : (g > 64 ? 64 : g);
+  hipLaunchKernelGGL(count_partials_kernel, dim3(g), dim3(256), 0, stream, partials, n, counter);
+  return hipGetLastError();
+}
+
+namespace {
+// from this many workgroups on a counted launch leaves its counts in partials (a second, tiny launch) instead of one
+// atomic per workgroup on one address (~12 ns each, one after the other)
+constexpr int kPartialsMinBlocks = 2048;
 
 template <int OP>
 hipError_t launch_ewise_op(const EwiseParams& prm, hipStream_t stream)
@@ -276,10 +300,18 @@ hipError_t launch_ewise_op(const EwiseParams& prm, hipStream_t stream)
     int cap = both ? 256 * 16 : (tables ? 256 * 256 : 0x7fffffff);
     if (env().ewise_max_blocks > 0)
       cap = env().ewise_max_blocks;
-    hipLaunchKernelGGL((ewise_kernel<OP, true>), dim3(grid_for(n4, block, cap)), dim3(block), 0, stream, prm);
+    const int grid = grid_for(n4, block, cap);
+    EwiseParams main = prm;
+    const bool by_partials = prm.count && prm.partials && grid >= kPartialsMinBlocks && grid <= prm.partials_cap;
+    if (!by_partials)
+      main.partials = nullptr;
+    hipLaunchKernelGGL((ewise_kernel<OP, true>), dim3(grid), dim3(block), 0, stream, main);
+    if (by_partials)
+      (void)launch_count_partials(prm.partials, grid, prm.n_undefined, stream);
     const int tail = prm.n - n4 * 4;
     if (tail > 0) {
       EwiseParams t = prm;
+      t.partials = nullptr;
       t.n = tail;
       t.in0 = prm.in0 + n4 * 4;
       t.in1 = prm.in1 ? prm.in1 + n4 * 4 : nullptr;
@@ -289,7 +321,9 @@ hipError_t launch_ewise_op(const EwiseParams& prm, hipStream_t stream)
       hipLaunchKernelGGL((ewise_kernel<OP, false>), dim3(1), dim3(64), 0, stream, t);
     }
   } else {
-    hipLaunchKernelGGL((ewise_kernel<OP, false>), dim3(grid_for(prm.n, block, 256 * 16)), dim3(block), 0, stream, prm);
+    EwiseParams q = prm;
+    q.partials = nullptr;
+    hipLaunchKernelGGL((ewise_kernel<OP, false>), dim3(grid_for(prm.n, block, 256 * 16)), dim3(block), 0, stream, q);
   }
   return hipGetLastError();
 }

@@ -60,6 +60,10 @@ struct EwiseParams
   const float* in2; // ps | p field
   float* out;
   u64* n_undefined; // device counter (may be null when count == 0)
+  // big launches: the workgroups leave their counts in partials[blockIdx.x] (plain stores) and a one-workgroup kernel
+  // behind the launch adds them up -- no queue of same-address atomics (mifc_device.h: undefined-cell counting)
+  unsigned int* partials;
+  int partials_cap;
 };
 
 hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream);
@@ -149,9 +153,12 @@ struct PwParams
   u64* n_undefined;
   const float* values; // values2classes: device copy of the class limits
   int nvalues;
+  unsigned int* partials; // see EwiseParams
+  int partials_cap;
 };
 hipError_t launch_pointwise(const PwParams& prm, hipStream_t stream);
 // sum and number of the defined cells (cvtemp compute 3, 4)
+hipError_t launch_count_partials(const unsigned int* partials, int n, u64* counter, hipStream_t stream);
 hipError_t launch_mean_defined(const float* f, int n, int all_defined, float undef, double* sum, unsigned long long* count, hipStream_t stream);
 
 // ------------------------------------ reductions over ensemble members

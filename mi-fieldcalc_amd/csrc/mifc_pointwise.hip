@@ -559,8 +559,10 @@ __global__ __launch_bounds__(256) void pointwise_kernel(const PwParams P)
       bad += (st == PW_UNDEF || st == PW_SKIP) ? 1u : 0u;
     }
   }
-  if (P.count)
-    wave_count_add(P.n_undefined, bad);
+  if (P.count && P.partials)
+    block_count_store(P.partials + blockIdx.x, bad); // big launch: added up by count_partials_kernel behind it
+  else
+    block_count_add(P.count ? P.n_undefined : nullptr, bad); // one atomic per workgroup
 }
 
 inline bool aligned16(const void* p)
@@ -581,10 +583,17 @@ hipError_t launch_pw(const PwParams& prm, hipStream_t stream)
     const int n4 = prm.n >> 2;
     int g = (n4 + block - 1) / block;
     g = g < 1 ? 1 : (g > cap ? cap : g);
-    hipLaunchKernelGGL((pointwise_kernel<OP, true>), dim3(g), dim3(block), 0, stream, prm);
+    PwParams main = prm;
+    const bool by_partials = prm.count && prm.partials && g >= 2048 && g <= prm.partials_cap; // see mifc_ewise.hip
+    if (!by_partials)
+      main.partials = nullptr;
+    hipLaunchKernelGGL((pointwise_kernel<OP, true>), dim3(g), dim3(block), 0, stream, main);
+    if (by_partials)
+      (void)launch_count_partials(prm.partials, g, prm.n_undefined, stream);
     const int tail = prm.n - n4 * 4;
     if (tail > 0) {
       PwParams t = prm;
+      t.partials = nullptr;
       t.n = tail;
       for (int k = 0; k < NIN; ++k)
         t.in[k] = prm.in[k] + n4 * 4;
@@ -594,7 +603,9 @@ hipError_t launch_pw(const PwParams& prm, hipStream_t stream)
   } else {
     int g = (prm.n + block - 1) / block;
     g = g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g);
-    hipLaunchKernelGGL((pointwise_kernel<OP, false>), dim3(g), dim3(block), 0, stream, prm);
+    PwParams q = prm;
+    q.partials = nullptr;
+    hipLaunchKernelGGL((pointwise_kernel<OP, false>), dim3(g), dim3(block), 0, stream, q);
   }
   return hipGetLastError();
 }

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256) void stencil_cell_kernel(const StencilParams P
       }
     }
   }
-  if (CHECK && P.n_undefined)
-    wave_count_add(P.n_undefined + lev, bad);
+  if (CHECK)
+    block_count_add(P.n_undefined ? P.n_undefined + lev : nullptr, bad); // one atomic per workgroup
 }
 
 template <int OP>

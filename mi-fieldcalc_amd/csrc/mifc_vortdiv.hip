@@ -1025,6 +1025,12 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
   static_assert(4 * NS <= 64, "the edge scalars of a level are one dword per lane");
   __shared__ v4f srow[NB][NS][2][64];       // [buffer][slot][u | v][lane]
   __shared__ float sedge[NB][64];           // [buffer][4 * slot + 2 * (u | v) + (west | east)]
+  // undefined counts of a level: the compute waves add theirs into LDS, compute wave 0 hands the total of level l to the
+  // global counter after the barrier of level l + 1 -- ONE global atomic per workgroup and level (same-address atomics are
+  // served one after the other: a masked field made the per-wave atomics cost twice the kernel)
+  __shared__ unsigned int sbad[2];
+  if (CHECK && threadIdx.x < 2)
+    sbad[threadIdx.x] = 0; // ordered before the first use by the barrier of the first level
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int bid = blockIdx.x;
@@ -1102,6 +1108,8 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
         b_next = (b_next + 1 == NB) ? 0 : b_next + 1;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land in LDS after the workgroup has gone
+      if (CHECK)
+        asm volatile("s_barrier" ::: "memory"); // the compute waves' barrier before the last level's count leaves
     };
     if (lw == 0)
       walk(std::true_type());
@@ -1132,6 +1140,14 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
   for (int lev = lev0; lev < lev1; ++lev) {
     // the LDS reads of the previous level are consumed (their values went into the stores); stores stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (CHECK && P.n_undefined && wave == 0 && lane == 0 && lev > lev0) { // the count of the previous level is complete
+      const int q = (lev - 1 - lev0) & 1;
+      const unsigned int n = sbad[q];
+      if (n != 0) {
+        atomicAdd(P.n_undefined + (lev - 1), (u64)n);
+        sbad[q] = 0; // the next adds into this slot come after the next barrier
+      }
+    }
     if (computes) {
       const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
       const v4f uc = srow[buf][slot][0][lane], vc = srow[buf][slot][1][lane];
@@ -1201,10 +1217,21 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
             store4<NT>(dv + oo + nx, d4);
         }
       }
-      if (CHECK && P.n_undefined && !all)
-        wave_count_add(P.n_undefined + lev, bad);
+      if (CHECK && P.n_undefined && !all && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+        const unsigned int n = wave_sum(bad);
+        if (lane == 0)
+          atomicAdd(&sbad[(lev - lev0) & 1], n);
+      }
     }
     buf = (buf + 1 == NB) ? 0 : buf + 1;
+  }
+  if (CHECK) { // the last level's count
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (P.n_undefined && wave == 0 && lane == 0 && lev1 > lev0) {
+      const unsigned int n = sbad[(lev1 - 1 - lev0) & 1];
+      if (n != 0)
+        atomicAdd(P.n_undefined + (lev1 - 1), (u64)n);
+    }
   }
 }
 

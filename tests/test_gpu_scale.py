@@ -681,3 +681,56 @@ def test_config1_vectorabs_256x256_through_the_cxx_signature(oracle, tmp_path, m
     got = np.fromfile(fout, np.float32).reshape(ny, nx)
     ok, e, f_e = oracle.call("vectorabs", nx, ny, u, v, fdefined=flag)
     assert ok and _bits_equal(got, e) and int(res.stdout.split()[0]) == f_e
+
+
+@pytest.mark.parametrize("mode", ["all", "some"])
+def test_counts_of_launches_above_the_partial_count_threshold(gpu_ctx, oracle, mode):
+    """From 2 048 workgroups (2.1 M cells) on, the one-shot elementwise / pointwise kernels leave their undefined counts in
+    per-workgroup slots that a small kernel adds up (no queue of same-address atomics): values, counts and flags of a
+    2048 x 1100 field with undefined values everywhere equal the reference's."""
+    grid = (2048, 1100)
+    ew = [c for c in cases.ewise_cases(grids=[grid], modes=(mode,)) if c["op"] in ("vectorabs", "hlevelhum", "cvhum")]
+    seen, keep = set(), []
+    for c in ew:
+        if c["op"] not in seen:
+            seen.add(c["op"])
+            keep.append(c)
+    pw = _pick(cases.catalogue_cases(grids=[grid], modes=(mode,)), {"cvtemp": {1}, "fieldOPERfield": {1}, "kIndex": {1}, "showalterIndex": {1}})
+    seen = set()
+    for c in pw:
+        if c["op"] not in seen:
+            seen.add(c["op"])
+            keep.append(c)
+    assert len(keep) >= 6
+    _run_big(gpu_ctx, oracle, keep, device=True)
+
+
+def test_masked_level_batch_counts(gpu_ctx, oracle, mifc_env):
+    """A level batch whose undefined values are EVERYWHERE (every wave of every workgroup has something to count): the
+    split-role kernel adds a level's counts up in LDS and hands one total per workgroup to the level's counter; the first
+    level-walking form counts per wave.  Counts (flags) and values of sampled levels equal the reference's, both forms."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 1440, 720, 13
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 2025, nlev=nlev)
+    rng = np.random.default_rng(7)
+    for l in range(nlev):  # level 3 stays clean, level 5 is undefined altogether, the others carry 0.1 .. 30 %
+        frac = 0.0 if l == 3 else (1.0 if l == 5 else (0.001, 0.02, 0.3)[l % 3])
+        m = rng.random((ny, nx)) < frac
+        u[l][m] = cases.UNDEF
+        v[l][rng.random((ny, nx)) < frac / 2] = np.nan
+    du, dv, dxm, dym = (torch.from_numpy(a).cuda() for a in (u, v, xm, ym))
+    flags = np.full(nlev, fc.SOME_DEFINED, np.int32)
+    for split in ("1", "0"):
+        mifc_env("MIFC_VORTDIV_SPLIT", split)
+        (rv, dg), fo = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags)
+        for l in range(nlev):
+            ok, rv_e, f1 = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=fc.SOME_DEFINED)
+            ok2, dv_e, f2 = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=fc.SOME_DEFINED)
+            assert ok and ok2 and f1 == f2 == fo[l], (split, l, f1, fo[l])
+            if l in (0, 3, 5, nlev - 1):
+                assert _bits_equal(rv[l].cpu().numpy(), rv_e) and _bits_equal(dg[l].cpu().numpy(), dv_e)
