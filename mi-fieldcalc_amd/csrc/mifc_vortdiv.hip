@@ -507,13 +507,15 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
   decode_oneshot(P, seq, lev, rblock, wc);
 
   const int nx = P.nx;
-  const int jl = P.lo + rblock * 4 + wave; // local row of this wave
-  if (jl >= P.hi)
-    return;
+  // a wave past the computed range works on the last computed row and keeps the result to itself: it stays for the
+  // workgroup-wide count at the end (one atomic per workgroup: mifc_device.h, undefined-cell counting)
+  const int jl_raw = P.lo + rblock * 4 + wave; // local row of this wave
+  const bool live = jl_raw < P.hi;
+  const int jl = live ? jl_raw : P.hi - 1;
   const int j = P.j0 + jl;
   const int col = wc * 256 + lane * 4;
-  const bool act = col < nx;
-  const int col_c = act ? col : nx - 4;
+  const bool act = live && col < nx;
+  const int col_c = (col < nx) ? col : nx - 4;
   int east_col = wc * 256 + 256;
   if (east_col > nx)
     east_col = nx;
@@ -610,8 +612,8 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
         store4<NT>(dv + oo + nx, d4);
     }
   }
-  if (CHECK && P.n_undefined)
-    wave_count_add(P.n_undefined + lev, bad);
+  if (CHECK)
+    block_count_add(P.n_undefined ? P.n_undefined + lev : nullptr, bad); // every wave of the workgroup is on this level
 }
 
 // ---------------------------------------------------------------------------
@@ -670,6 +672,11 @@ __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsP
   }
   su[wave][lane] = uc;
   sv[wave][lane] = vc;
+  // undefined count of the workgroup: the compute waves add theirs into LDS and tick an arrival counter (a wave's LDS
+  // operations are in order), the last one to arrive hands the total to the level's counter -- one atomic per workgroup
+  __shared__ unsigned int s_cnt[2]; // [0] total, [1] compute waves that have added theirs
+  if (CHECK && threadIdx.x < 2)
+    s_cnt[threadIdx.x] = 0;
   __syncthreads();
   if (!computes)
     return;
@@ -741,8 +748,20 @@ __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsP
         store4<NT>(dv + oo + nx, d4);
     }
   }
-  if (CHECK && P.n_undefined)
-    wave_count_add(P.n_undefined + lev, bad);
+  if (CHECK && P.n_undefined) {
+    const unsigned int n = (__builtin_amdgcn_ballot_w64(bad != 0) != 0) ? wave_sum(bad) : 0u;
+    if (lane == 0) {
+      if (n != 0)
+        atomicAdd(&s_cnt[0], n);
+      const int rows_left = P.hi - (P.lo + rblock * RB); // compute waves of this workgroup
+      const unsigned int ncompute = (unsigned int)(rows_left < RB ? rows_left : RB);
+      if (atomicAdd(&s_cnt[1], 1u) + 1u == ncompute) {
+        const unsigned int total = atomicAdd(&s_cnt[0], 0u);
+        if (total != 0)
+          atomicAdd(P.n_undefined + lev, (u64)total);
+      }
+    }
+  }
 }
 
 
@@ -772,6 +791,11 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
   constexpr int TR = HALO ? NW - 2 : NW; // rows of the tile
   __shared__ v4f su[2][TR + 2][64];
   __shared__ v4f sv[2][TR + 2][64];
+  // undefined counts of a level: added up in LDS, handed to the level's counter by thread 0 after the barrier of the next
+  // level -- one global atomic per workgroup and level (mifc_device.h: undefined-cell counting)
+  __shared__ unsigned int sbad[2];
+  if (CHECK && threadIdx.x < 2)
+    sbad[threadIdx.x] = 0; // ordered before the first use by the barrier of the first level
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
   const int bid = blockIdx.x;
@@ -904,6 +928,14 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
       // can only overwrite buffer b again after the barrier of the level in between, which every wave reaches
       // with its reads of b consumed.
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (CHECK && P.n_undefined && threadIdx.x == 0 && lev > lev0) { // the count of the previous level is complete
+        const int q = (lev - 1 - lev0) & 1;
+        const unsigned int n = sbad[q];
+        if (n != 0) {
+          atomicAdd(P.n_undefined + (lev - 1), (u64)n);
+          sbad[q] = 0; // the next adds into this slot come after the next barrier
+        }
+      }
       if (computes) {
         const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
         // two passes, vorticity then divergence, each taking its rows from LDS when it needs them and storing at
@@ -987,12 +1019,23 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
               store4<NT>(dv + oo + nx, d4);
           }
         }
-        if (CHECK && P.n_undefined && !all)
-          wave_count_add(P.n_undefined + lev, bad);
+        if (CHECK && P.n_undefined && !all && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+          const unsigned int n = wave_sum(bad);
+          if (lane == 0)
+            atomicAdd(&sbad[(lev - lev0) & 1], n);
+        }
       }
     }
   }
 chunk_done:;
+  if (CHECK) { // the last level's count
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (P.n_undefined && threadIdx.x == 0 && lev1 > lev0) {
+      const unsigned int n = sbad[(lev1 - 1 - lev0) & 1];
+      if (n != 0)
+        atomicAdd(P.n_undefined + (lev1 - 1), (u64)n);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------

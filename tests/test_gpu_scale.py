@@ -734,3 +734,44 @@ def test_masked_level_batch_counts(gpu_ctx, oracle, mifc_env):
             assert ok and ok2 and f1 == f2 == fo[l], (split, l, f1, fo[l])
             if l in (0, 3, 5, nlev - 1):
                 assert _bits_equal(rv[l].cpu().numpy(), rv_e) and _bits_equal(dg[l].cpu().numpy(), dv_e)
+
+
+@pytest.mark.parametrize("tune", [None, "K=1", "K=2", "K=2,RB=14", "R=8"])
+def test_masked_single_level_counts(gpu_ctx, oracle, tune, mifc_env):
+    """One and two levels with undefined values everywhere through the forms a shallow launch takes (one-shot, one-shot
+    tiles, row-walking): every workgroup hands ONE total to the level's counter; counts, flags and values equal the reference's.
+    Then a deep batch with a single output (the first level-walking form, per-level counts added up in LDS)."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+
+    if tune:
+        mifc_env("MIFC_VORTDIV_TUNE", tune)
+    nx, ny = 1440, 725  # a last row block that is not full
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 4711, nlev=2)
+    rng = np.random.default_rng(11)
+    u[0][rng.random((ny, nx)) < 0.02] = cases.UNDEF
+    v[1][rng.random((ny, nx)) < 0.3] = np.nan
+    du, dv, dxm, dym = (torch.from_numpy(a).cuda() for a in (u, v, xm, ym))
+    expect = []
+    for l in range(2):
+        ok, rv_e, f1 = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=fc.SOME_DEFINED)
+        ok2, dv_e, f2 = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=fc.SOME_DEFINED)
+        assert ok and ok2 and f1 == f2
+        expect.append((rv_e, dv_e, f1))
+    for nl in (1, 2):
+        (rv, dg), fo = gpu_ctx.vortdiv_levels(du[:nl], dv[:nl], dxm, dym, fdefined=[fc.SOME_DEFINED] * nl)
+        for l in range(nl):
+            assert fo[l] == expect[l][2]
+            assert _bits_equal(rv[l].cpu().numpy(), expect[l][0]) and _bits_equal(dg[l].cpu().numpy(), expect[l][1])
+    if tune is None:
+        nlev = 9
+        uu = np.repeat(u[:1], nlev, axis=0).copy()
+        vv = np.repeat(v[1:2], nlev, axis=0).copy()
+        duu, dvv = torch.from_numpy(uu).cuda(), torch.from_numpy(vv).cuda()
+        ok, rv_e, f1 = oracle.call("relvort", nx, ny, uu[0], vv[0], xm, ym, fdefined=fc.SOME_DEFINED)
+        (rv, none), fo = gpu_ctx.vortdiv_levels(duu, dvv, dxm, dym, fdefined=[fc.SOME_DEFINED] * nlev, want=("rvort",))
+        assert none is None and all(f == f1 for f in fo)
+        assert _bits_equal(rv[0].cpu().numpy(), rv_e) and _bits_equal(rv[nlev - 1].cpu().numpy(), rv_e)

@@ -63,6 +63,11 @@ def main():
         out = rv.view(NLEV * NY, NX)
         t2 = timed(lambda: ctx.vectorabs(tall_u, tall_v, fdefined=fc.SOME_DEFINED, out=out))
         print("%-44s %10.4f" % ("vectorabs tested (sync call), " + name, t2))
+        # one level (the reference's per-field call pattern), enqueue form: kernel + memset, no host round trip
+        u1, v1 = u[:1], dv[:1]
+        f1 = np.full(1, fc.SOME_DEFINED, np.int32)
+        t3 = timed(lambda: ctx.vortdiv_levels_enqueue(u1, v1, dxm, dym, rv[:1], dg[:1], fdefined=f1, n_undefined=cnt[:1]), inner=20)
+        print("%-44s %10.4f" % ("vortdiv tested, ONE level, " + name, t3))
         del u
 
 
