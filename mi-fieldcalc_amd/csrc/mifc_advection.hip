@@ -49,12 +49,14 @@ __global__ __launch_bounds__(256) void advection_oneshot_kernel(const StencilPar
   const int rblock = rem / uW;
   const int wc = rem - rblock * uW;
   const int nx = P.nx, ny = P.ny_global;
-  const int j = 1 + rblock * 4 + wave; // rows 1 .. ny-2 are computed
-  if (j > ny - 2)
-    return;
+  // a wave past the last computed row works on that row and keeps the result to itself: it stays for the workgroup-wide
+  // count at the end (one atomic per workgroup: mifc_device.h, undefined-cell counting)
+  const int j_raw = 1 + rblock * 4 + wave; // rows 1 .. ny-2 are computed
+  const bool live = j_raw <= ny - 2;
+  const int j = live ? j_raw : ny - 2;
   const int col = wc * 256 + lane * 4;
-  const bool act = col < nx;
-  const int col_c = act ? col : nx - 4;
+  const bool act = live && col < nx;
+  const int col_c = (col < nx) ? col : nx - 4;
   int east_col = wc * 256 + 256;
   if (east_col > nx)
     east_col = nx;
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(256) void advection_oneshot_kernel(const StencilPar
     if (j == ny - 2)
       __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(out + oo + nx));
   }
-  if (CHECK && P.n_undefined)
-    wave_count_add(P.n_undefined + lev, bad);
+  if (CHECK)
+    block_count_add(P.n_undefined ? P.n_undefined + lev : nullptr, bad); // every wave of the workgroup is on this level
 }
 
 inline bool a16(const void* p)
