@@ -1066,9 +1066,10 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
   constexpr int NS = TR + 2;                // row slots per level: slot s holds tile row s - 1
   constexpr int KMAX = (NS + NL - 1) / NL;  // row slots per loader wave
   static_assert(4 * NS <= 64, "the edge scalars of a level are one dword per lane");
+  static_assert(NL >= 2, "loader 0 gathers the edge scalars, the last loader hands the undefined counts over");
   __shared__ v4f srow[NB][NS][2][64];       // [buffer][slot][u | v][lane]
   __shared__ float sedge[NB][64];           // [buffer][4 * slot + 2 * (u | v) + (west | east)]
-  // undefined counts of a level: the compute waves add theirs into LDS, compute wave 0 hands the total of level l to the
+  // undefined counts of a level: the compute waves add theirs into LDS, the last loader hands the total of level l to the
   // global counter after the barrier of level l + 1 -- ONE global atomic per workgroup and level (same-address atomics are
   // served one after the other: a masked field made the per-wave atomics cost twice the kernel)
   __shared__ unsigned int sbad[2];
@@ -1145,14 +1146,33 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
       for (int k = 0; k < PF; ++k)
         issue(lev0 + k, k);
       int b_next = PF % NB; // buffer of level lev + PF
+      // the last loader also hands a level's undefined count (added up in LDS by the compute waves) to the global counter,
+      // one level late: it has nothing else to do between its loads and the next barrier, a compute wave would make the
+      // whole workgroup wait for the LDS round trip.  Its atomic is one more entry in this wave's vmcnt queue, younger
+      // than the loads the next wait is about: that wait can only get stricter.
+      auto hand_over = [&](int lev_done) {
+        if (CHECK && !EDGE && lw == NL - 1 && P.n_undefined && lane == 0) {
+          const int q = (lev_done - lev0) & 1;
+          const unsigned int n = sbad[q];
+          if (n != 0) {
+            atomicAdd(P.n_undefined + lev_done, (u64)n);
+            sbad[q] = 0; // the next adds into this slot come after the next barrier
+          }
+        }
+      };
       for (int lev = lev0; lev < lev1; ++lev) {
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PF - 1) * L) : "memory");
         issue(lev + PF, b_next);
         b_next = (b_next + 1 == NB) ? 0 : b_next + 1;
+        if (lev > lev0)
+          hand_over(lev - 1); // complete since the barrier above
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land in LDS after the workgroup has gone
-      if (CHECK)
-        asm volatile("s_barrier" ::: "memory"); // the compute waves' barrier before the last level's count leaves
+      if (CHECK) {
+        asm volatile("s_barrier" ::: "memory"); // the compute waves' last barrier
+        if (lev1 > lev0)
+          hand_over(lev1 - 1);
+      }
     };
     if (lw == 0)
       walk(std::true_type());
@@ -1183,14 +1203,6 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
   for (int lev = lev0; lev < lev1; ++lev) {
     // the LDS reads of the previous level are consumed (their values went into the stores); stores stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (CHECK && P.n_undefined && wave == 0 && lane == 0 && lev > lev0) { // the count of the previous level is complete
-      const int q = (lev - 1 - lev0) & 1;
-      const unsigned int n = sbad[q];
-      if (n != 0) {
-        atomicAdd(P.n_undefined + (lev - 1), (u64)n);
-        sbad[q] = 0; // the next adds into this slot come after the next barrier
-      }
-    }
     if (computes) {
       const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
       const v4f uc = srow[buf][slot][0][lane], vc = srow[buf][slot][1][lane];
@@ -1268,14 +1280,8 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
     }
     buf = (buf + 1 == NB) ? 0 : buf + 1;
   }
-  if (CHECK) { // the last level's count
+  if (CHECK) // the last level's adds are complete: the last loader hands its total over
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (P.n_undefined && wave == 0 && lane == 0 && lev1 > lev0) {
-      const unsigned int n = sbad[(lev1 - 1 - lev0) & 1];
-      if (n != 0)
-        atomicAdd(P.n_undefined + (lev1 - 1), (u64)n);
-    }
-  }
 }
 
 struct Tuning
