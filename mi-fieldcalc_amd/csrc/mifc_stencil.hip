@@ -177,6 +177,44 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
   return true;
 }
 
+// Final value(s) of owned cell i (flat local index) after fillEdges, and its contribution to the undefined count.
+template <int OP, bool CHECK>
+__device__ __forceinline__ void cell_one(const StencilParams& P, const float* __restrict__ f0, const float* __restrict__ f1, long i, bool all, int jmax,
+                                         CellOut& o, unsigned int& bad)
+{
+  const int nx = P.nx;
+  const int jl = (int)(i / nx);
+  const int c = (int)(i - (long)jl * nx);
+  const int j = P.j0 + jl;
+  // where the value of this cell comes from after fillEdges
+  const int jj = j < 1 ? 1 : (j > jmax ? jmax : j);
+  const int cc = c < 1 ? 1 : (c > nx - 2 ? nx - 2 : c);
+  const long p = (long)(jj - P.j0) * nx + cc;
+  o.o0 = P.undef;
+  o.o1 = P.undef;
+  const bool ok = stencil_raw<OP, CHECK>(P, f0, f1, p, all, o);
+  if (!ok) {
+    o.o0 = P.undef;
+    o.o1 = P.undef;
+  }
+  // TFP rejects |grad T| == 0 cells, the Q-vector pass tests its inputs, whatever the input flag says
+  if (CHECK && (!all || OP == ST_TFP || OP == ST_QVEC_X || OP == ST_QVEC_Y)) {
+    // Count over the raw loop range, with the wrapped neighbours the flat
+    // loop sees at the edge columns (Appendix A #6).
+    const long gi = (long)j * nx + c;
+    const long ng = (long)nx * P.ny_global;
+    const bool in_range = (OP == ST_GRAD_X) ? (gi >= 1 && gi < ng - 1) : (j >= 1 && j <= jmax);
+    if (in_range) {
+      if (p == i) {
+        bad += ok ? 0u : 1u;
+      } else {
+        CellOut dummy;
+        bad += stencil_raw<OP, CHECK>(P, f0, f1, i, all, dummy) ? 0u : 1u;
+      }
+    }
+  }
+}
+
 // One lane per owned cell; blockIdx.y = level.
 template <int OP, bool CHECK>
 __global__ __launch_bounds__(256) void stencil_cell_kernel(const StencilParams P)
@@ -195,36 +233,208 @@ __global__ __launch_bounds__(256) void stencil_cell_kernel(const StencilParams P
   const long cell_begin = (P.row_end > P.row_begin) ? (long)P.row_begin * nx : 0;
   const long cell_end = (P.row_end > P.row_begin) ? (long)P.row_end * nx : n_local;
   for (long i = cell_begin + (long)blockIdx.x * blockDim.x + threadIdx.x; i < cell_end; i += (long)gridDim.x * blockDim.x) {
-    const int jl = (int)(i / nx);
-    const int c = (int)(i - (long)jl * nx);
-    const int j = P.j0 + jl;
-    // where the value of this cell comes from after fillEdges
-    const int jj = j < 1 ? 1 : (j > jmax ? jmax : j);
-    const int cc = c < 1 ? 1 : (c > nx - 2 ? nx - 2 : c);
-    const long p = (long)(jj - P.j0) * nx + cc;
-    CellOut o = {P.undef, P.undef};
-    const bool ok = stencil_raw<OP, CHECK>(P, f0, f1, p, all, o);
-    if (!ok) {
-      o.o0 = P.undef;
-      o.o1 = P.undef;
-    }
+    CellOut o;
+    cell_one<OP, CHECK>(P, f0, f1, i, all, jmax, o, bad);
     out0[i] = o.o0;
     if ((OP == ST_VORTDIV || OP == ST_IGWIND) && out1)
       out1[i] = o.o1;
+  }
+  if (CHECK)
+    block_count_add(P.n_undefined ? P.n_undefined + lev : nullptr, bad); // one atomic per workgroup
+}
 
-    // TFP rejects |grad T| == 0 cells, the Q-vector pass tests its inputs, whatever the input flag says
-    if (CHECK && (!all || OP == ST_TFP || OP == ST_QVEC_X || OP == ST_QVEC_Y)) {
-      // Count over the raw loop range, with the wrapped neighbours the flat
-      // loop sees at the edge columns (Appendix A #6).
-      const long gi = (long)j * nx + c;
-      const long ng = (long)nx * P.ny_global;
-      const bool in_range = (OP == ST_GRAD_X) ? (gi >= 1 && gi < ng - 1) : (j >= 1 && j <= jmax);
-      if (in_range) {
-        if (p == i) {
-          bad += ok ? 0u : 1u;
+// ---------------------------------------------------------------------------
+// Wind operators on a width that is NOT a multiple of 4 (949 x 1069, say): the row-walking / level-walking kernels
+// want 16-byte aligned rows, the one-lane-per-cell kernel above moves one dword per lane and instruction and divides
+// per cell (39 % of 8 TB/s for the fused pair where the aligned kernels reach 60 % on a grid of that size).  The
+// reference's loop is FLAT (i - 1, i + 1, i - nx, i + nx: section header), so this kernel is too: a lane takes four
+// consecutive flat cells, 16 bytes per load and store at dword alignment (the hardware takes them), the rows above and
+// below as the same loads nx cells earlier / later, x-neighbours from the adjacent lanes (DPP) -- consecutive lanes
+// hold consecutive cells whatever the width.  What is not a plain interior cell goes through cell_one(): the first
+// and last column of every row and rows 0 / ny-1 (their values come from a clamped position), the lanes whose group
+// reaches over the first or last loadable row, and the last, partial wave of a level.
+typedef float v4f_s __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) U4
+{
+  v4f_s v;
+};
+__device__ __forceinline__ v4f_s ldu4(const float* p)
+{
+  return reinterpret_cast<const U4*>(p)->v;
+}
+__device__ __forceinline__ void stu4(float* p, const v4f_s v)
+{
+  U4 t;
+  t.v = v;
+  *reinterpret_cast<U4*>(p) = t;
+}
+__device__ __forceinline__ float flat_from_lower_lane(float keep_if_none, float x)
+{
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float flat_from_upper_lane(float keep_if_none, float x)
+{
+  return __builtin_bit_cast(float,
+                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
+
+// Units are (level, 1024 consecutive cells); the blocks of the 1-D launch are dealt round-robin to the 8 XCDs, so unit
+// seq = (b % 8) * per_xcd + b / 8 puts CONSECUTIVE units on one XCD: the rows above and below a unit's cells belong to the
+// units next to it and are then served by that XCD's L2 instead of crossing the fabric three times.
+template <int OP, bool CHECK> // ST_RELVORT, ST_ABSVORT, ST_DIVERGENCE, ST_VORTDIV
+__global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, const int blocks_per_level, const int n_units, const int per_xcd)
+{
+  constexpr bool WANT_V = OP != ST_DIVERGENCE, WANT_D = OP == ST_DIVERGENCE || OP == ST_VORTDIV;
+  const int seq = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (seq >= n_units)
+    return;
+  const int lev = seq / blocks_per_level;
+  const int blk = seq - lev * blocks_per_level;
+  const int nx = P.nx;
+  const int n_local = nx * P.ny_local; // fits 32 bits: the launcher checks
+  const float* __restrict__ u = P.f0 + (size_t)lev * P.in_level_stride;
+  const float* __restrict__ v = P.f1 + (size_t)lev * P.in_level_stride;
+  float* out0 = P.out0 + (size_t)lev * P.out_level_stride;
+  float* out1 = P.out1 ? P.out1 + (size_t)lev * P.out_level_stride : nullptr;
+  const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
+  const int jmax = P.ny_global - 2;
+  const float undef = P.undef;
+  unsigned int bad = 0;
+  const int cell_begin = (P.row_end > P.row_begin) ? P.row_begin * nx : 0;
+  const int cell_end = (P.row_end > P.row_begin) ? P.row_end * nx : n_local;
+  // loadable flat range of the level: a slab has a halo row above / below its owned rows
+  const int lo_idx = (P.j0 > 0) ? -nx : 0;
+  const int hi_idx = n_local + ((P.j0 + P.ny_local < P.ny_global) ? nx : 0) - 1;
+  const int lane = threadIdx.x & 63;
+  // all lanes of a wave stay together (the x-neighbours come from the adjacent lanes)
+  const int w0 = cell_begin + 4 * (blk * 256 + (int)(threadIdx.x & ~63u));
+  if (w0 < cell_end) {
+    const int i0 = w0 + 4 * lane;
+    const bool whole_wave = w0 + 4 * 64 <= cell_end; // wave-uniform
+    // rows above / below as whole groups: only if the group does not reach over the loadable range
+    const bool vec = whole_wave && i0 - nx >= lo_idx && i0 + nx + 3 <= hi_idx;
+    CellOut o[4];
+    bool done[4] = {false, false, false, false};
+    unsigned int nocount = 0;
+    if (whole_wave) {
+      const int is = vec ? i0 - nx : i0, in = vec ? i0 + nx : i0;
+      const v4f_s uc = ldu4(u + i0), vc = ldu4(v + i0);
+      const v4f_s us = ldu4(u + is), un = ldu4(u + in);
+      v4f_s vs = vc, vn = vc;
+      if (WANT_D) {
+        vs = ldu4(v + is);
+        vn = ldu4(v + in);
+      }
+      const v4f_s xm4 = ldu4(P.xmapr + i0), ym4 = ldu4(P.ymapr + i0);
+      v4f_s fc4 = xm4;
+      if (OP == ST_ABSVORT)
+        fc4 = ldu4(P.fcoriolis + i0);
+      // the cell before the wave's first and behind its last: lanes 0 and 63 keep what they load themselves
+      int e = (lane == 63) ? i0 + 4 : i0 - 1;
+      e = e < lo_idx ? lo_idx : (e > hi_idx ? hi_idx : e);
+      const float eu = u[e], ev = v[e];
+      const float uW = flat_from_lower_lane(eu, uc.w), vW = flat_from_lower_lane(ev, vc.w);
+      const float uE = flat_from_upper_lane(eu, uc.x), vE = flat_from_upper_lane(ev, vc.x);
+      const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
+      const float vcx[6] = {vW, vc.x, vc.y, vc.z, vc.w, vE};
+      const int jl0 = i0 / nx; // one division per group
+      const int c0 = i0 - jl0 * nx;
+      // raw values of the flat loop for every cell of a computed row -- the first and last column included: with their
+      // wrapped neighbours they are what the reference COUNTS there (Appendix A #6)
+      CellOut raw[4];
+      bool row_ok[4];
+      int col[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int c = c0 + k, jl = jl0;
+        if (c >= nx) {
+          c -= nx;
+          jl += 1;
+        }
+        const int j = P.j0 + jl;
+        col[k] = c;
+        row_ok[k] = vec && j >= 1 && j <= jmax;
+        const float vw = vcx[k], ve = vcx[k + 2], uw = ucx[k], ue = ucx[k + 2];
+        bool ok = true;
+        if (CHECK) // :1861 == :1895 == :1927
+          ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef));
+        raw[k].o0 = undef;
+        raw[k].o1 = undef;
+        if (ok) {
+          if (OP == ST_RELVORT)
+            raw[k].o0 = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
+          else if (OP == ST_ABSVORT)
+            raw[k].o0 = f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]);
+          else if (OP == ST_DIVERGENCE)
+            raw[k].o0 = f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]);
+          else {
+            raw[k].o0 = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
+            raw[k].o1 = f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]);
+          }
+        }
+        if (CHECK && !all && !ok && row_ok[k])
+          bad += 1;
+      }
+      // fillEdges, column part: column 0 takes the raw value of column 1 (the next flat cell), column nx-1 that of
+      // column nx-2 (the previous one) -- from this lane's group or from the adjacent lane's
+      const float nx0 = flat_from_upper_lane(0.f, raw[0].o0), nx1 = flat_from_upper_lane(0.f, raw[0].o1);
+      const float pv0 = flat_from_lower_lane(0.f, raw[3].o0), pv1 = flat_from_lower_lane(0.f, raw[3].o1);
+      const int vec_i = vec ? 1 : 0;
+      const bool next_vec = __builtin_amdgcn_update_dpp(0, vec_i, 0x130 /*wave_shl:1*/, 0xf, 0xf, false) != 0 && lane != 63;
+      const bool prev_vec = __builtin_amdgcn_update_dpp(0, vec_i, 0x138 /*wave_shr:1*/, 0xf, 0xf, false) != 0 && lane != 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!row_ok[k])
+          continue; // rows 0 / ny-1 and the groups at the ends of the loadable range: the per-cell path below
+        if (col[k] == 0) {
+          if (k < 3) {
+            o[k] = raw[k + 1];
+            done[k] = true;
+          } else if (next_vec) {
+            o[k].o0 = nx0;
+            o[k].o1 = nx1;
+            done[k] = true;
+          } else {
+            nocount |= 1u << k; // value through the per-cell path, counted here already
+          }
+        } else if (col[k] == nx - 1) {
+          if (k > 0) {
+            o[k] = raw[k - 1];
+            done[k] = true;
+          } else if (prev_vec) {
+            o[k].o0 = pv0;
+            o[k].o1 = pv1;
+            done[k] = true;
+          } else {
+            nocount |= 1u << k;
+          }
         } else {
-          CellOut dummy;
-          bad += stencil_raw<OP, CHECK>(P, f0, f1, i, all, dummy) ? 0u : 1u;
+          o[k] = raw[k];
+          done[k] = true;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!done[k] && i0 + k < cell_end) {
+        unsigned int b = 0;
+        cell_one<OP, CHECK>(P, u, v, (long)(i0 + k), all, jmax, o[k], b);
+        if (!((nocount >> k) & 1u))
+          bad += b;
+      }
+    }
+    if (i0 + 3 < cell_end) {
+      stu4(out0 + i0, v4f_s{o[0].o0, o[1].o0, o[2].o0, o[3].o0});
+      if (OP == ST_VORTDIV && out1)
+        stu4(out1 + i0, v4f_s{o[0].o1, o[1].o1, o[2].o1, o[3].o1});
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i0 + k < cell_end) {
+          out0[i0 + k] = o[k].o0;
+          if (OP == ST_VORTDIV && out1)
+            out1[i0 + k] = o[k].o1;
         }
       }
     }
@@ -259,6 +469,40 @@ hipError_t launch_cell(const StencilParams& prm, hipStream_t stream)
   return hipGetLastError();
 }
 
+template <int OP>
+hipError_t launch_wind_flat4(const StencilParams& prm, hipStream_t stream)
+{
+  const long rows = (prm.row_end > prm.row_begin) ? (long)(prm.row_end - prm.row_begin) : (long)prm.ny_local;
+  const long cells = rows * prm.nx;
+  const int blocks_per_level = (int)((cells + 1023) / 1024);
+  // levels in slices that keep the unit count in 31 bits
+  const int max_levels = (int)(0x3fffffffL / blocks_per_level) > 0 ? (int)(0x3fffffffL / blocks_per_level) : 1;
+  for (int l0 = 0; l0 < prm.nlev; l0 += max_levels) {
+    StencilParams p = prm;
+    const int nl = (prm.nlev - l0 > max_levels) ? max_levels : (prm.nlev - l0);
+    p.f0 = prm.f0 + (size_t)l0 * prm.in_level_stride;
+    p.f1 = prm.f1 + (size_t)l0 * prm.in_level_stride;
+    p.out0 = prm.out0 + (size_t)l0 * prm.out_level_stride;
+    p.out1 = prm.out1 ? prm.out1 + (size_t)l0 * prm.out_level_stride : nullptr;
+    p.all_defined = prm.all_defined ? prm.all_defined + l0 : nullptr;
+    p.n_undefined = prm.n_undefined ? prm.n_undefined + l0 : nullptr;
+    const int n_units = blocks_per_level * nl;
+    const int per_xcd = (n_units + 7) / 8;
+    if (prm.every_level_all_defined)
+      hipLaunchKernelGGL((wind_flat4_kernel<OP, false>), dim3((unsigned)(per_xcd * 8)), dim3(256), 0, stream, p, blocks_per_level, n_units, per_xcd);
+    else
+      hipLaunchKernelGGL((wind_flat4_kernel<OP, true>), dim3((unsigned)(per_xcd * 8)), dim3(256), 0, stream, p, blocks_per_level, n_units, per_xcd);
+  }
+  return hipGetLastError();
+}
+
+// the flat kernel wants dword-aligned fields (any float array is), 32-bit cell indices and at least four columns
+inline bool wind_flat4_applies(const StencilParams& prm)
+{
+  return !env().force_cell_kernel && prm.nx >= 4 && prm.ny_global >= 3 && (long)prm.nx * (prm.ny_local + 2) < 0x7fffff00L && prm.f1 &&
+         (prm.op != ST_ABSVORT || prm.fcoriolis);
+}
+
 } // namespace
 
 hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, bool* handled); // mifc_vortdiv.hip
@@ -289,13 +533,13 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
   }
   switch (prm.op) {
   case ST_RELVORT:
-    return launch_cell<ST_RELVORT>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_RELVORT>(prm, stream) : launch_cell<ST_RELVORT>(prm, stream);
   case ST_ABSVORT:
-    return launch_cell<ST_ABSVORT>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_ABSVORT>(prm, stream) : launch_cell<ST_ABSVORT>(prm, stream);
   case ST_DIVERGENCE:
-    return launch_cell<ST_DIVERGENCE>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_DIVERGENCE>(prm, stream) : launch_cell<ST_DIVERGENCE>(prm, stream);
   case ST_VORTDIV:
-    return launch_cell<ST_VORTDIV>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_VORTDIV>(prm, stream) : launch_cell<ST_VORTDIV>(prm, stream);
   case ST_GRAD_X:
     return launch_cell<ST_GRAD_X>(prm, stream);
   case ST_GRAD_Y:

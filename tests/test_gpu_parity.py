@@ -382,6 +382,34 @@ def test_vortdiv_levels_matches_per_level_reference_calls(gpu_ctx, oracle, nx, n
     assert none is None and cases.same_bits(dv2.cpu().numpy(), dv_e, nan_payload=False) and np.array_equal(fo3, fo_e)
 
 
+@pytest.mark.parametrize("nx,ny,nlev", [(949, 23, 4), (1001, 13, 3), (258, 9, 2), (6, 300, 2), (4, 3, 1), (5, 4, 3), (1443, 7, 2)])
+@pytest.mark.parametrize("force_cell", ["0", "1"])
+def test_wind_operators_on_ragged_widths(gpu_ctx, oracle, nx, ny, nlev, force_cell, mifc_env):
+    """Widths that are not a multiple of 4 take the flat four-cells-per-lane kernel (dword-aligned 16-byte accesses, rows
+    above / below as the same loads nx cells away, first / last columns and rows through the per-cell path); with
+    MIFC_FORCE_CELL_KERNEL=1 the one-lane-per-cell kernel.  Fused pair, single outputs and absvort, mixed flags per level."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    mifc_env("MIFC_FORCE_CELL_KERNEL", force_cell)
+    u, v, xm, ym, flags = _levels_inputs(nx, ny, nlev, 777 + nx)
+    rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
+    du, dvv, dxm, dym = (torch.from_numpy(a).cuda() for a in (u, v, xm, ym))
+    (rv, dv), fo = gpu_ctx.vortdiv_levels(du, dvv, dxm, dym, fdefined=flags)
+    assert cases.same_bits(rv.cpu().numpy(), rv_e, nan_payload=False) and cases.same_bits(dv.cpu().numpy(), dv_e, nan_payload=False)
+    assert np.array_equal(fo, fo_e)
+    (rv2, none), fo2 = gpu_ctx.vortdiv_levels(du, dvv, dxm, dym, fdefined=flags, want=("rvort",))
+    assert none is None and cases.same_bits(rv2.cpu().numpy(), rv_e, nan_payload=False) and np.array_equal(fo2, fo_e)
+    (none, dv2), fo3 = gpu_ctx.vortdiv_levels(du, dvv, dxm, dym, fdefined=flags, want=("diverg",))
+    assert none is None and cases.same_bits(dv2.cpu().numpy(), dv_e, nan_payload=False) and np.array_equal(fo3, fo_e)
+    _, _, fcor = synth.grid_maps(nx, ny)
+    for l in range(nlev):
+        ok, av_e, f = oracle.call("absvort", nx, ny, u[l], v[l], xm, ym, fcor, fdefined=int(flags[l]))
+        res = gpu_ctx.absvort(du[l], dvv[l], dxm, dym, torch.from_numpy(fcor).cuda(), fdefined=int(flags[l]))
+        assert ok and res is not None and res[1] == f and cases.same_bits(res[0].cpu().numpy(), av_e, nan_payload=False)
+
+
 def test_vortdiv_levels_all_defined_fast_path(gpu_ctx, oracle):
     u, v, xm, ym, flags = _levels_inputs(256, 40, 8, 777, mixed=False)
     rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
@@ -465,7 +493,7 @@ def test_vortdiv_enqueue_counts(gpu_ctx, oracle):
 
 
 # ------------------------------------------------------------------ row slabs
-@pytest.mark.parametrize("nx,ny,nslab", [(64, 40, 4), (260, 23, 3), (512, 64, 8), (33, 17, 2)])
+@pytest.mark.parametrize("nx,ny,nslab", [(64, 40, 4), (260, 23, 3), (512, 64, 8), (33, 17, 2), (949, 41, 3), (258, 20, 4)])
 @pytest.mark.parametrize("mode", ["all", "some"])
 @pytest.mark.parametrize("tune", [None, "K=2", "R=8", "K=4,D=1", "K=4,RB=6,D=2"])
 def test_vortdiv_row_slabs_equal_whole_field(gpu_ctx, oracle, nx, ny, nslab, mode, tune, mifc_env):
