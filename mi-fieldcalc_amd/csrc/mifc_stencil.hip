@@ -177,6 +177,52 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
   return true;
 }
 
+// The one-input operators of stencil_raw() from VALUES (the flat four-cells-per-lane kernel has them in registers); the
+// same expressions, the same tests.  ST_GRAD_X is not here: its count runs over another range (cell_one).
+template <int OP, bool CHECK>
+__device__ __forceinline__ bool scalar_from_values(bool all, float undef, float s, float w, float c, float e, float n, float xmf, float ymf, float fcf,
+                                                   CellOut& o)
+{
+  if (OP == ST_GRAD_Y) { // :2027-2028
+    if (CHECK && !(all || (is_def(s, undef) && is_def(n, undef))))
+      return false;
+    o.o0 = half_prod(ymf, n - s);
+    return true;
+  }
+  if (OP == ST_GRAD_LAP || OP == ST_GVORT) {
+    if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(c, undef) && is_def(e, undef) && is_def(n, undef)))) // :2053, :729
+      return false;
+    const double xm = xmf, ym = ymf;
+    if (OP == ST_GRAD_LAP) { // :2054-2056, second differences rounded to float first
+      const float d2x = (float)((double)w - 2.0 * (double)c + (double)e);
+      const float d2y = (float)((double)s - 2.0 * (double)c + (double)n);
+      o.o0 = (float)(4.0 * (0.25 * xm * xm * (double)d2x + 0.25 * ym * ym * (double)d2y));
+    } else { // :730-731, second differences stay double
+      const float g4 = (float)((double)MIFC_K_G * 4.);
+      const double d2x = (double)w - 2. * (double)c + (double)e;
+      const double d2y = (double)s - 2. * (double)c + (double)n;
+      o.o0 = (float)((0.25 * xm * xm * d2x + 0.25 * ym * ym * d2y) * (double)g4 / (double)fcf);
+    }
+    return true;
+  }
+  if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef)))) // :2039, :660, :693, :1534
+    return false;
+  if (OP == ST_GRAD_ABS) { // :2040-2042
+    const float dfdx = half_prod(xmf, e - w);
+    const float dfdy = half_prod(ymf, n - s);
+    o.o0 = absval(dfdx, dfdy);
+  } else if (OP == ST_GWIND_X) { // :661
+    o.o0 = (float)(-0.5 * (double)ymf * (double)(n - s) * (double)MIFC_K_G / (double)fcf);
+  } else if (OP == ST_GWIND_Y) { // :694
+    o.o0 = (float)(0.5 * (double)xmf * (double)(e - w) * (double)MIFC_K_G / (double)fcf);
+  } else { // ST_IGWIND :1535-1536
+    const double fc = fcf;
+    o.o0 = (float)(-0.5 * (double)ymf * (double)(n - s) / fc);
+    o.o1 = (float)(0.5 * (double)xmf * (double)(e - w) / fc);
+  }
+  return true;
+}
+
 // Final value(s) of owned cell i (flat local index) after fillEdges, and its contribution to the undefined count.
 template <int OP, bool CHECK>
 __device__ __forceinline__ void cell_one(const StencilParams& P, const float* __restrict__ f0, const float* __restrict__ f1, long i, bool all, int jmax,
@@ -282,10 +328,13 @@ __device__ __forceinline__ float flat_from_upper_lane(float keep_if_none, float 
 // Units are (level, 1024 consecutive cells); the blocks of the 1-D launch are dealt round-robin to the 8 XCDs, so unit
 // seq = (b % 8) * per_xcd + b / 8 puts CONSECUTIVE units on one XCD: the rows above and below a unit's cells belong to the
 // units next to it and are then served by that XCD's L2 instead of crossing the fabric three times.
-template <int OP, bool CHECK> // ST_RELVORT, ST_ABSVORT, ST_DIVERGENCE, ST_VORTDIV
+template <int OP, bool CHECK> // the wind operators and the one-input operators but ST_GRAD_X
 __global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, const int blocks_per_level, const int n_units, const int per_xcd)
 {
-  constexpr bool WANT_V = OP != ST_DIVERGENCE, WANT_D = OP == ST_DIVERGENCE || OP == ST_VORTDIV;
+  constexpr bool WIND = OP == ST_RELVORT || OP == ST_ABSVORT || OP == ST_DIVERGENCE || OP == ST_VORTDIV;
+  constexpr bool WANT_D = OP == ST_DIVERGENCE || OP == ST_VORTDIV;
+  constexpr bool USE_FC = OP == ST_ABSVORT || OP == ST_GWIND_X || OP == ST_GWIND_Y || OP == ST_GVORT || OP == ST_IGWIND;
+  constexpr bool TWO_OUT = OP == ST_VORTDIV || OP == ST_IGWIND;
   const int seq = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
   if (seq >= n_units)
     return;
@@ -293,8 +342,8 @@ __global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, 
   const int blk = seq - lev * blocks_per_level;
   const int nx = P.nx;
   const int n_local = nx * P.ny_local; // fits 32 bits: the launcher checks
-  const float* __restrict__ u = P.f0 + (size_t)lev * P.in_level_stride;
-  const float* __restrict__ v = P.f1 + (size_t)lev * P.in_level_stride;
+  const float* __restrict__ u = P.f0 + (size_t)lev * P.in_level_stride;                    // the one-input operators: the field
+  const float* __restrict__ v = WIND ? P.f1 + (size_t)lev * P.in_level_stride : u;
   float* out0 = P.out0 + (size_t)lev * P.out_level_stride;
   float* out1 = P.out1 ? P.out1 + (size_t)lev * P.out_level_stride : nullptr;
   const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
@@ -319,7 +368,8 @@ __global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, 
     unsigned int nocount = 0;
     if (whole_wave) {
       const int is = vec ? i0 - nx : i0, in = vec ? i0 + nx : i0;
-      const v4f_s uc = ldu4(u + i0), vc = ldu4(v + i0);
+      const v4f_s uc = ldu4(u + i0);
+      const v4f_s vc = WIND ? ldu4(v + i0) : uc;
       const v4f_s us = ldu4(u + is), un = ldu4(u + in);
       v4f_s vs = vc, vn = vc;
       if (WANT_D) {
@@ -328,12 +378,13 @@ __global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, 
       }
       const v4f_s xm4 = ldu4(P.xmapr + i0), ym4 = ldu4(P.ymapr + i0);
       v4f_s fc4 = xm4;
-      if (OP == ST_ABSVORT)
+      if (USE_FC)
         fc4 = ldu4(P.fcoriolis + i0);
       // the cell before the wave's first and behind its last: lanes 0 and 63 keep what they load themselves
       int e = (lane == 63) ? i0 + 4 : i0 - 1;
       e = e < lo_idx ? lo_idx : (e > hi_idx ? hi_idx : e);
-      const float eu = u[e], ev = v[e];
+      const float eu = u[e];
+      const float ev = WIND ? v[e] : eu;
       const float uW = flat_from_lower_lane(eu, uc.w), vW = flat_from_lower_lane(ev, vc.w);
       const float uE = flat_from_upper_lane(eu, uc.x), vE = flat_from_upper_lane(ev, vc.x);
       const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
@@ -357,20 +408,28 @@ __global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, 
         row_ok[k] = vec && j >= 1 && j <= jmax;
         const float vw = vcx[k], ve = vcx[k + 2], uw = ucx[k], ue = ucx[k + 2];
         bool ok = true;
-        if (CHECK) // :1861 == :1895 == :1927
-          ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef));
         raw[k].o0 = undef;
         raw[k].o1 = undef;
-        if (ok) {
-          if (OP == ST_RELVORT)
-            raw[k].o0 = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
-          else if (OP == ST_ABSVORT)
-            raw[k].o0 = f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]);
-          else if (OP == ST_DIVERGENCE)
-            raw[k].o0 = f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]);
-          else {
-            raw[k].o0 = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
-            raw[k].o1 = f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]);
+        if (WIND) {
+          if (CHECK) // :1861 == :1895 == :1927
+            ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef));
+          if (ok) {
+            if (OP == ST_RELVORT)
+              raw[k].o0 = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
+            else if (OP == ST_ABSVORT)
+              raw[k].o0 = f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]);
+            else if (OP == ST_DIVERGENCE)
+              raw[k].o0 = f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]);
+            else {
+              raw[k].o0 = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
+              raw[k].o1 = f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]);
+            }
+          }
+        } else {
+          ok = scalar_from_values<OP, CHECK>(all, undef, us[k], uw, ucx[k + 1], ue, un[k], xm4[k], ym4[k], fc4[k], raw[k]);
+          if (!ok) {
+            raw[k].o0 = undef;
+            raw[k].o1 = undef;
           }
         }
         if (CHECK && !all && !ok && row_ok[k])
@@ -426,14 +485,14 @@ __global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, 
     }
     if (i0 + 3 < cell_end) {
       stu4(out0 + i0, v4f_s{o[0].o0, o[1].o0, o[2].o0, o[3].o0});
-      if (OP == ST_VORTDIV && out1)
+      if (TWO_OUT && out1)
         stu4(out1 + i0, v4f_s{o[0].o1, o[1].o1, o[2].o1, o[3].o1});
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (i0 + k < cell_end) {
           out0[i0 + k] = o[k].o0;
-          if (OP == ST_VORTDIV && out1)
+          if (TWO_OUT && out1)
             out1[i0 + k] = o[k].o1;
         }
       }
@@ -481,7 +540,7 @@ hipError_t launch_wind_flat4(const StencilParams& prm, hipStream_t stream)
     StencilParams p = prm;
     const int nl = (prm.nlev - l0 > max_levels) ? max_levels : (prm.nlev - l0);
     p.f0 = prm.f0 + (size_t)l0 * prm.in_level_stride;
-    p.f1 = prm.f1 + (size_t)l0 * prm.in_level_stride;
+    p.f1 = prm.f1 ? prm.f1 + (size_t)l0 * prm.in_level_stride : nullptr;
     p.out0 = prm.out0 + (size_t)l0 * prm.out_level_stride;
     p.out1 = prm.out1 ? prm.out1 + (size_t)l0 * prm.out_level_stride : nullptr;
     p.all_defined = prm.all_defined ? prm.all_defined + l0 : nullptr;
@@ -499,8 +558,10 @@ hipError_t launch_wind_flat4(const StencilParams& prm, hipStream_t stream)
 // the flat kernel wants dword-aligned fields (any float array is), 32-bit cell indices and at least four columns
 inline bool wind_flat4_applies(const StencilParams& prm)
 {
-  return !env().force_cell_kernel && prm.nx >= 4 && prm.ny_global >= 3 && (long)prm.nx * (prm.ny_local + 2) < 0x7fffff00L && prm.f1 &&
-         (prm.op != ST_ABSVORT || prm.fcoriolis);
+  const bool wind = prm.op == ST_RELVORT || prm.op == ST_ABSVORT || prm.op == ST_DIVERGENCE || prm.op == ST_VORTDIV;
+  const bool needs_fc = prm.op == ST_ABSVORT || prm.op == ST_GWIND_X || prm.op == ST_GWIND_Y || prm.op == ST_GVORT || prm.op == ST_IGWIND;
+  return !env().force_cell_kernel && prm.nx >= 4 && prm.ny_global >= 3 && (long)prm.nx * (prm.ny_local + 2) < 0x7fffff00L && (!wind || prm.f1) &&
+         (!needs_fc || prm.fcoriolis) && prm.xmapr && prm.ymapr;
 }
 
 } // namespace
@@ -543,19 +604,19 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
   case ST_GRAD_X:
     return launch_cell<ST_GRAD_X>(prm, stream);
   case ST_GRAD_Y:
-    return launch_cell<ST_GRAD_Y>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_GRAD_Y>(prm, stream) : launch_cell<ST_GRAD_Y>(prm, stream);
   case ST_GRAD_ABS:
-    return launch_cell<ST_GRAD_ABS>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_GRAD_ABS>(prm, stream) : launch_cell<ST_GRAD_ABS>(prm, stream);
   case ST_GRAD_LAP:
-    return launch_cell<ST_GRAD_LAP>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_GRAD_LAP>(prm, stream) : launch_cell<ST_GRAD_LAP>(prm, stream);
   case ST_GWIND_X:
-    return launch_cell<ST_GWIND_X>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_GWIND_X>(prm, stream) : launch_cell<ST_GWIND_X>(prm, stream);
   case ST_GWIND_Y:
-    return launch_cell<ST_GWIND_Y>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_GWIND_Y>(prm, stream) : launch_cell<ST_GWIND_Y>(prm, stream);
   case ST_GVORT:
-    return launch_cell<ST_GVORT>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_GVORT>(prm, stream) : launch_cell<ST_GVORT>(prm, stream);
   case ST_IGWIND:
-    return launch_cell<ST_IGWIND>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_IGWIND>(prm, stream) : launch_cell<ST_IGWIND>(prm, stream);
   case ST_ADVECTION:
     return launch_cell<ST_ADVECTION>(prm, stream);
   case ST_JACOBIAN:

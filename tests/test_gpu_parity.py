@@ -903,3 +903,17 @@ def test_winddir_extension(gpu_ctx):
     dd, flag = gpu_ctx.winddir(uu, v, fdefined=SOME)
     bad = (uu == cases.UNDEF) | np.isnan(uu)
     assert flag == SOME and np.all(dd[bad] == cases.UNDEF) and np.all(dd[~bad] != cases.UNDEF)
+
+
+@pytest.mark.parametrize("force_cell", ["0", "1"])
+def test_one_input_stencils_on_ragged_widths(gpu_ctx, oracle, force_cell, mifc_env):
+    """gradient (all four), geostrophic wind / vorticity, ilevelgwind on widths that are not a multiple of 4, large enough for
+    whole waves of the flat four-cells-per-lane kernel (and the one-lane-per-cell kernel under MIFC_FORCE_CELL_KERNEL=1)."""
+    mifc_env("MIFC_FORCE_CELL_KERNEL", force_cell)
+    ops = ("gradient", "plevelgwind_xcomp", "plevelgwind_ycomp", "plevelgvort", "ilevelgwind", "relvort", "divergence", "absvort")
+    n = 0
+    for case in cases.stencil_cases(grids=[(949, 23), (1001, 7), (258, 9), (6, 40)]):
+        if case["op"] in ops:
+            _check_case(gpu_ctx, oracle, case, device=True)
+            n += 1
+    assert n >= 4 * 4 * 11
