@@ -51,6 +51,15 @@ def main():
         flags = np.full(nlev, fc.ALL_DEFINED, np.int32)
         t = timed(lambda: ctx.stencil_levels("gradient3", du, None, dxm, dym, fdefined=flags, out0=rv))
         print("%-10d %-34s %10.4f %10.1f" % (nx, "|grad f| (stencil_levels), ALL", t, n * 8 / t / 1e6 / 80.0))
+        if os.environ.get("RAGGED_F1"):  # the rest of the stencil family (still on the per-cell / level-by-level paths for these widths)
+            t = timed(lambda: ctx.stencil_levels("jacobian", du, dv, dxm, dym, fdefined=flags, out0=rv))
+            print("%-10d %-34s %10.4f %10.1f" % (nx, "jacobian (stencil_levels), ALL", t, n * 12 / t / 1e6 / 80.0))
+            t = timed(lambda: ctx.stencil_levels_ex("advection", du, du, dv, xmapr=dxm, ymapr=dym, scalar=1.0, fdefined=flags, out0=rv))
+            print("%-10d %-34s %10.4f %10.1f" % (nx, "advection (stencil_levels_ex), ALL", t, n * 16 / t / 1e6 / 80.0))
+            t = timed(lambda: ctx.stencil_levels_ex("thermalFrontParameter", du, xmapr=dxm, ymapr=dym, fdefined=flags, out0=rv))
+            print("%-10d %-34s %10.4f %10.1f" % (nx, "TFP (stencil_levels_ex), ALL", t, n * 8 / t / 1e6 / 80.0))
+            t = timed(lambda: ctx.stencil_levels_ex("shapiro2_filter", du, fdefined=flags, out0=rv))
+            print("%-10d %-34s %10.4f %10.1f" % (nx, "shapiro2 (stencil_levels_ex), ALL", t, n * 8 / t / 1e6 / 80.0))
 
 
 if __name__ == "__main__":
