@@ -1095,17 +1095,19 @@ static bool fused2_enabled()
 
 // thermalFrontParameter pass by pass on device pointers: |grad T| into the context's scratch, then the
 // front parameter; the second pass takes its "all defined" from the flag the first one returned (:2286)
+// Device pointers; nlev levels at once (fields nx * ny floats apart, the intermediate batch in the context's scratch): each
+// pass is ONE launch over the levels, the second takes every level's "all defined" from what the first returned for it.
 static int tfp_two_passes(mifc_ctx* c, int nx, int ny, const float* d_tx, const float* d_xm, const float* d_ym, float* d_out, int* fdefined,
-                          float undef)
+                          float undef, int nlev = 1)
 {
   const size_t n = (size_t)nx * ny;
-  if (!ensure_slot(c, 8, n * sizeof(float)))
+  if (!ensure_slot(c, 8, n * (size_t)nlev * sizeof(float)))
     return 0;
   float* d_absdelt = static_cast<float*>(c->slot[8]);
-  const StencilCall pass1 = {mifc::ST_GRAD_ABS, nx, ny, 1, d_tx, nullptr, d_xm, d_ym, nullptr, d_absdelt, nullptr};
+  const StencilCall pass1 = {mifc::ST_GRAD_ABS, nx, ny, nlev, d_tx, nullptr, d_xm, d_ym, nullptr, d_absdelt, nullptr};
   if (!run_stencil(c, pass1, fdefined, undef, MIFC_MEM_DEVICE))
     return 0;
-  const StencilCall pass2 = {mifc::ST_TFP, nx, ny, 1, d_tx, d_absdelt, d_xm, d_ym, nullptr, d_out, nullptr};
+  const StencilCall pass2 = {mifc::ST_TFP, nx, ny, nlev, d_tx, d_absdelt, d_xm, d_ym, nullptr, d_out, nullptr};
   return run_stencil(c, pass2, fdefined, undef, MIFC_MEM_DEVICE);
 }
 
@@ -1275,6 +1277,8 @@ static int f1_levels_fallback(mifc_ctx* c, int op, int nx, int ny, int nlev, con
                               const float* fc, const float* level_p, int compute, float* out0, int* fdefined, float undef)
 {
   const size_t n = (size_t)nx * ny;
+  if (op == MIFC_OP_TFP && nlev > 1) // widths the one-launch kernel does not take: the two passes, each over all levels
+    return tfp_two_passes(c, nx, ny, f0, xm, ym, out0, fdefined, undef, nlev);
   for (int l = 0; l < nlev; ++l) {
     int rc;
     if (op == MIFC_OP_TFP)

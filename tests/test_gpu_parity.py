@@ -805,7 +805,7 @@ def test_one_launch_kernels_equal_their_multi_pass_paths_on_a_large_field(gpu_ct
 
 
 # ------------------------------------------------------------------ the f1 operators over level batches (shared map factors)
-@pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 5), (129, 21, 3), (1440, 37, 6), (240, 9, 4)])
+@pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 5), (129, 21, 3), (1440, 37, 6), (240, 9, 4), (949, 12, 5)])
 @pytest.mark.parametrize("device", [False, True])
 def test_stencil_levels_ex_f1_operators(gpu_ctx, oracle, nx, ny, nlev, device):
     """mifc_stencil_levels_ex: advection, thermalFrontParameter, plevelqvector (pressure per level) and
