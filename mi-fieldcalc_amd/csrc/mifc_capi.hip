@@ -1377,6 +1377,42 @@ int mifc_stencil_levels_ex(mifc_ctx* c, int op, int nx, int ny, int nlev, const 
         fdefined[l] = MIFC_ALL_DEFINED; // :2171
       return 1;
     }
+    // widths the one-launch kernel does not take: the sweep-by-sweep path over the levels of each flag group (five launches
+    // per group whatever the number of levels), in place on the output batch like the reference (:2099-2104)
+    if (nlev > 1 && nlev <= 65535 && n <= 0x7fffffffu) {
+      if (!ensure_slot(c, 9, nb * sizeof(float)))
+        return 0;
+      const bool any_tested = n_all < nlev;
+      if (any_tested && !ensure_slot(c, 7, 2 * nb))
+        return 0;
+      if (dst != d0)
+        MIFC_HIP(c, hipMemcpyAsync(dst, d0, nb * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      MIFC_HIP(c, hipMemcpyAsync(c->d_levels, order.data(), sizeof(int) * (size_t)nlev, hipMemcpyHostToDevice, c->stream));
+      mifc::ShapiroParams SP;
+      SP.nx = nx;
+      SP.ny = ny;
+      SP.undef = undef;
+      SP.f1 = dst;
+      SP.f2 = static_cast<float*>(c->slot[9]);
+      SP.mask_x = any_tested ? static_cast<unsigned char*>(c->slot[7]) : nullptr;
+      SP.mask_y = any_tested ? static_cast<unsigned char*>(c->slot[7]) + nb : nullptr;
+      if (n_all > 0) {
+        SP.all_defined = 1;
+        MIFC_LAUNCH(c, mifc::launch_shapiro2_levels(SP, n_all, c->d_levels, c->stream));
+      }
+      if (any_tested) {
+        SP.all_defined = 0;
+        MIFC_LAUNCH(c, mifc::launch_shapiro2_levels(SP, nlev - n_all, c->d_levels + n_all, c->stream));
+      }
+      if (dst != dout)
+        MIFC_HIP(c, hipMemcpyAsync(dout, dst, nb * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+      if (!fetch_out(c, 5, out0, nb, memkind))
+        return 0;
+      MIFC_HIP(c, hipStreamSynchronize(c->stream));
+      for (int l = 0; l < nlev; ++l)
+        fdefined[l] = MIFC_ALL_DEFINED; // :2171
+      return 1;
+    }
   } else {
     mifc::Fused2Params F;
     std::memset(&F, 0, sizeof F);

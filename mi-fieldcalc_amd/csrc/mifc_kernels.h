@@ -263,6 +263,7 @@ struct ShapiroParams
   unsigned char* mask_y;
 };
 hipError_t launch_shapiro2(const ShapiroParams& prm, hipStream_t stream);
+hipError_t launch_shapiro2_levels(const ShapiroParams& prm, int n_launch_levels, const int* levels, hipStream_t stream); // batches, see mifc_shapiro.hip
 // The four sweeps in one launch, src -> dst (two different arrays); nx % 4 == 0, 16-byte aligned.
 bool shapiro2_fused_supported(int nx, int ny, const float* src, const float* dst);
 hipError_t launch_shapiro2_fused(int nx, int ny, int all_defined, float undef, const float* src, float* dst, hipStream_t stream);

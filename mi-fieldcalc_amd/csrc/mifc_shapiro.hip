@@ -21,9 +21,14 @@ namespace mifc {
 
 namespace {
 
+// blockIdx.y = position in the launch's level list (levels == nullptr: the level itself); a level is n cells
 __global__ __launch_bounds__(256) void shapiro_masks_kernel(const float* __restrict__ f, int nx, int n, float undef, unsigned char* __restrict__ m1,
-                                                            unsigned char* __restrict__ m2)
+                                                            unsigned char* __restrict__ m2, const int* __restrict__ levels)
 {
+  const size_t off = (size_t)(levels ? levels[blockIdx.y] : (int)blockIdx.y) * (size_t)n;
+  f += off;
+  m1 += off;
+  m2 += off;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const bool c = is_def(f[i], undef);
     m1[i] = (i >= 1 && i < n - 1 && c && is_def(f[i - 1], undef) && is_def(f[i + 1], undef)) ? 1 : 0;     // :2142
@@ -34,9 +39,14 @@ __global__ __launch_bounds__(256) void shapiro_masks_kernel(const float* __restr
 // dst = sweep(src) along x (STEP = 1, edge = first/last column) or y (STEP = nx, edge = first/last row)
 template <bool ALL, bool ALONG_X>
 __global__ __launch_bounds__(256) void shapiro_sweep_kernel(const float* __restrict__ src, float* __restrict__ dst, const unsigned char* __restrict__ mask,
-                                                            int nx, int ny, float s)
+                                                            int nx, int ny, float s, const int* __restrict__ levels)
 {
   const int n = nx * ny;
+  const size_t off = (size_t)(levels ? levels[blockIdx.y] : (int)blockIdx.y) * (size_t)n;
+  src += off;
+  dst += off;
+  if (!ALL)
+    mask += off;
   const int step = ALONG_X ? 1 : nx;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int row = i / nx;
@@ -279,24 +289,41 @@ hipError_t launch_shapiro2_fused_levels(int nx, int ny, int all_defined, float u
 
 hipError_t launch_shapiro2(const ShapiroParams& P, hipStream_t stream)
 {
+  return launch_shapiro2_levels(P, 1, nullptr, stream);
+}
+
+// The sweep-by-sweep path over n_launch_levels levels of a batch (P.f1, P.f2 and the masks are batches, a level nx * ny
+// apart; `levels` lists the levels of this launch or is null): five launches whatever the number of levels.
+hipError_t launch_shapiro2_levels(const ShapiroParams& P, int n_launch_levels, const int* levels, hipStream_t stream)
+{
   const int n = P.nx * P.ny;
-  if (n <= 0)
+  if (n <= 0 || n_launch_levels <= 0)
     return hipSuccess;
-  int grid = (n + 255) / 256;
-  if (grid > 65536)
-    grid = 65536;
-  if (!P.all_defined)
-    hipLaunchKernelGGL(shapiro_masks_kernel, dim3(grid), dim3(256), 0, stream, P.f1, P.nx, n, P.undef, P.mask_x, P.mask_y);
-  float s = 0.25f;
-  for (int pass = 0; pass < 2; ++pass) {
-    if (P.all_defined) {
-      hipLaunchKernelGGL((shapiro_sweep_kernel<true, true>), dim3(grid), dim3(256), 0, stream, P.f1, P.f2, nullptr, P.nx, P.ny, s);
-      hipLaunchKernelGGL((shapiro_sweep_kernel<true, false>), dim3(grid), dim3(256), 0, stream, P.f2, P.f1, nullptr, P.nx, P.ny, s);
-    } else {
-      hipLaunchKernelGGL((shapiro_sweep_kernel<false, true>), dim3(grid), dim3(256), 0, stream, P.f1, P.f2, P.mask_x, P.nx, P.ny, s);
-      hipLaunchKernelGGL((shapiro_sweep_kernel<false, false>), dim3(grid), dim3(256), 0, stream, P.f2, P.f1, P.mask_y, P.nx, P.ny, s);
+  int gx = (n + 255) / 256;
+  if (gx > 65536)
+    gx = 65536;
+  for (int l0 = 0; l0 < n_launch_levels; l0 += 65535) { // grid.y limit; an implicit numbering shifts the bases
+    const int nl = n_launch_levels - l0 > 65535 ? 65535 : n_launch_levels - l0;
+    const dim3 grid(gx, nl);
+    const size_t off = levels ? 0 : (size_t)l0 * (size_t)n;
+    const int* lv = levels ? levels + l0 : nullptr;
+    float* f1 = P.f1 + off;
+    float* f2 = P.f2 + off;
+    unsigned char* mx = P.mask_x ? P.mask_x + off : nullptr;
+    unsigned char* my = P.mask_y ? P.mask_y + off : nullptr;
+    if (!P.all_defined)
+      hipLaunchKernelGGL(shapiro_masks_kernel, grid, dim3(256), 0, stream, f1, P.nx, n, P.undef, mx, my, lv);
+    float s = 0.25f;
+    for (int pass = 0; pass < 2; ++pass) {
+      if (P.all_defined) {
+        hipLaunchKernelGGL((shapiro_sweep_kernel<true, true>), grid, dim3(256), 0, stream, f1, f2, nullptr, P.nx, P.ny, s, lv);
+        hipLaunchKernelGGL((shapiro_sweep_kernel<true, false>), grid, dim3(256), 0, stream, f2, f1, nullptr, P.nx, P.ny, s, lv);
+      } else {
+        hipLaunchKernelGGL((shapiro_sweep_kernel<false, true>), grid, dim3(256), 0, stream, f1, f2, mx, P.nx, P.ny, s, lv);
+        hipLaunchKernelGGL((shapiro_sweep_kernel<false, false>), grid, dim3(256), 0, stream, f2, f1, my, P.nx, P.ny, s, lv);
+      }
+      s = -0.25f;
     }
-    s = -0.25f;
   }
   return hipGetLastError();
 }
