@@ -212,10 +212,10 @@ def main():
     ap.add_argument("--no-check-variant", action="store_true", help="do not time the SOME_DEFINED (per-cell tests + counts) variant")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the tested variant is timed by default)")
     ap.add_argument("--settle-ms", type=float, default=40.0, help="untimed launches for this long before the W warm-up steps (clock ramp after idle); 0 = none")
-    ap.add_argument("--placement-pool", type=int, default=24,
+    ap.add_argument("--placement-pool", type=int, default=48,
                     help="the four arrays of the batch are chosen from a pool of this many arrays allocated in one go (mi-fieldcalc_amd/placement.py: which "
                          "combination of arrays a kernel streams decides its time by up to 12 %%); 0 = four allocations as they come")
-    ap.add_argument("--placement-tries", type=int, default=160, help="probes (index sets of the pool timed with the kernel) the search may spend; the fastest set is kept")
+    ap.add_argument("--placement-tries", type=int, default=240, help="probes (index sets of the pool timed with the kernel) the search may spend; the fastest set is kept")
     ap.add_argument("--level-stride", type=int, default=None, help="floats between levels (default: the library's mifc_batch_level_stride)")
     args = ap.parse_args()
 
@@ -281,13 +281,14 @@ def main():
     # once allocated, bimodal -- 0.40 / 0.435 ms -- and a property of the COMBINATION of arrays: DESIGN.md 4.1,
     # mi-fieldcalc_amd/placement.py).  A long-lived batch is therefore chosen from a pool of arrays allocated in one go:
     # structured and random index sets are probed with the kernel, then coordinate descent from the best; the rest of
-    # the pool is freed.  Outside every timed region; the report (incl. what the first four arrays of the pool --
+    # the pool is freed.  The pool is 48 arrays (27 GB): about one stretch of 24 consecutive allocations in six holds NO fast
+    # set at all (profiles/r02/experiments/placement_pools.txt), two stretches make that a 3 % event.  Outside every timed region; the report (incl. what the first four arrays of the pool --
     # "allocated in one go" -- would have given) goes into the JSON line.  --placement-pool 0: four allocations as they come.
     warmed = []
     from mi_fieldcalc_amd.placement import choose_search
     if args.placement_pool >= 4:
         (du, dv, rv, dg), placement = choose_search(lambda: ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride), 4, probe_batch,
-                                                    pool_size=args.placement_pool, max_probes=max(1, args.placement_tries), device=dev)
+                                                    pool_size=args.placement_pool, random_sets=48, max_probes=max(1, args.placement_tries), device=dev)
     else:
         du, dv, rv, dg = (ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride) for _ in range(4))
         placement = {"method": "four allocations as they come"}
