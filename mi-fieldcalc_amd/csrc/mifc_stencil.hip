@@ -331,8 +331,8 @@ __device__ __forceinline__ float flat_from_upper_lane(float keep_if_none, float 
 template <int OP, bool CHECK> // the wind operators and the one-input operators but ST_GRAD_X
 __global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, const int blocks_per_level, const int n_units, const int per_xcd)
 {
-  constexpr bool WIND = OP == ST_RELVORT || OP == ST_ABSVORT || OP == ST_DIVERGENCE || OP == ST_VORTDIV;
-  constexpr bool WANT_D = OP == ST_DIVERGENCE || OP == ST_VORTDIV;
+  constexpr bool WIND = OP == ST_RELVORT || OP == ST_ABSVORT || OP == ST_DIVERGENCE || OP == ST_VORTDIV || OP == ST_JACOBIAN; // two input fields
+  constexpr bool WANT_D = OP == ST_DIVERGENCE || OP == ST_VORTDIV || OP == ST_JACOBIAN;                                        // rows above / below of the second field too
   constexpr bool USE_FC = OP == ST_ABSVORT || OP == ST_GWIND_X || OP == ST_GWIND_Y || OP == ST_GVORT || OP == ST_IGWIND;
   constexpr bool TWO_OUT = OP == ST_VORTDIV || OP == ST_IGWIND;
   const int seq = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
@@ -410,7 +410,18 @@ __global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, 
         bool ok = true;
         raw[k].o0 = undef;
         raw[k].o1 = undef;
-        if (WIND) {
+        if (OP == ST_JACOBIAN) { // :2443-2451: all eight neighbours tested, four float-rounded partials, float combination
+          if (CHECK)
+            ok = all || (is_def(us[k], undef) && is_def(uw, undef) && is_def(ue, undef) && is_def(un[k], undef) && is_def(vs[k], undef) && is_def(vw, undef) &&
+                         is_def(ve, undef) && is_def(vn[k], undef));
+          if (ok) {
+            const float df1dx = half_prod(xm4[k], ue - uw);
+            const float df1dy = half_prod(ym4[k], un[k] - us[k]);
+            const float df2dx = half_prod(xm4[k], ve - vw);
+            const float df2dy = half_prod(ym4[k], vn[k] - vs[k]);
+            raw[k].o0 = df1dx * df2dy - df1dy * df2dx;
+          }
+        } else if (WIND) {
           if (CHECK) // :1861 == :1895 == :1927
             ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef));
           if (ok) {
@@ -558,7 +569,7 @@ hipError_t launch_wind_flat4(const StencilParams& prm, hipStream_t stream)
 // the flat kernel wants dword-aligned fields (any float array is), 32-bit cell indices and at least four columns
 inline bool wind_flat4_applies(const StencilParams& prm)
 {
-  const bool wind = prm.op == ST_RELVORT || prm.op == ST_ABSVORT || prm.op == ST_DIVERGENCE || prm.op == ST_VORTDIV;
+  const bool wind = prm.op == ST_RELVORT || prm.op == ST_ABSVORT || prm.op == ST_DIVERGENCE || prm.op == ST_VORTDIV || prm.op == ST_JACOBIAN;
   const bool needs_fc = prm.op == ST_ABSVORT || prm.op == ST_GWIND_X || prm.op == ST_GWIND_Y || prm.op == ST_GVORT || prm.op == ST_IGWIND;
   return !env().force_cell_kernel && prm.nx >= 4 && prm.ny_global >= 3 && (long)prm.nx * (prm.ny_local + 2) < 0x7fffff00L && (!wind || prm.f1) &&
          (!needs_fc || prm.fcoriolis) && prm.xmapr && prm.ymapr;
@@ -620,7 +631,7 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
   case ST_ADVECTION:
     return launch_cell<ST_ADVECTION>(prm, stream);
   case ST_JACOBIAN:
-    return launch_cell<ST_JACOBIAN>(prm, stream);
+    return wind_flat4_applies(prm) ? launch_wind_flat4<ST_JACOBIAN>(prm, stream) : launch_cell<ST_JACOBIAN>(prm, stream);
   case ST_TFP:
     return launch_cell<ST_TFP>(prm, stream);
   case ST_QVEC_X:

@@ -910,10 +910,10 @@ def test_one_input_stencils_on_ragged_widths(gpu_ctx, oracle, force_cell, mifc_e
     """gradient (all four), geostrophic wind / vorticity, ilevelgwind on widths that are not a multiple of 4, large enough for
     whole waves of the flat four-cells-per-lane kernel (and the one-lane-per-cell kernel under MIFC_FORCE_CELL_KERNEL=1)."""
     mifc_env("MIFC_FORCE_CELL_KERNEL", force_cell)
-    ops = ("gradient", "plevelgwind_xcomp", "plevelgwind_ycomp", "plevelgvort", "ilevelgwind", "relvort", "divergence", "absvort")
+    ops = ("gradient", "plevelgwind_xcomp", "plevelgwind_ycomp", "plevelgvort", "ilevelgwind", "relvort", "divergence", "absvort", "jacobian")
     n = 0
     for case in cases.stencil_cases(grids=[(949, 23), (1001, 7), (258, 9), (6, 40)]):
         if case["op"] in ops:
             _check_case(gpu_ctx, oracle, case, device=True)
             n += 1
-    assert n >= 4 * 4 * 11
+    assert n >= 4 * 4 * 12
