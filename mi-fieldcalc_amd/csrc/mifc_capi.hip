@@ -272,6 +272,8 @@ struct StencilCall
   const float* f2; // third input field (advection)
   float scale;     // advection, Q-vector
   float scale2;    // Q-vector
+  const float* scale_lev;  // Q-vector over a level batch: per-level tables on the device (or null)
+  const float* scale2_lev;
 };
 
 // count range of the raw loop -> what the flag is classified against
@@ -328,6 +330,8 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
   P.fcoriolis = stage_in(c, 4, sc.fc, n, memkind, &ok);
   P.scale = sc.scale;
   P.scale2 = sc.scale2;
+  P.scale_lev = sc.scale_lev;
+  P.scale2_lev = sc.scale2_lev;
   if (!ok || !ensure_levels(c, (size_t)sc.nlev))
     return 0;
   if (sc.op == mifc::ST_VORTDIV && !P.out0 && P.out1) {
@@ -1274,11 +1278,38 @@ int mifc_stencil_levels(mifc_ctx* c, int op, int nx, int ny, int nlev, const flo
 // (no tests) and the others.  Grids those kernels do not take (nx % 4 != 0, unaligned) go level by level
 // through the single-field entry points.
 static int f1_levels_fallback(mifc_ctx* c, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* xm, const float* ym,
-                              const float* fc, const float* level_p, int compute, float* out0, int* fdefined, float undef)
+                              const float* fc, const float* level_p, int compute, float* out0, int* fdefined, float undef,
+                              const float* tscale = nullptr, const float* cscale = nullptr)
 {
   const size_t n = (size_t)nx * ny;
   if (op == MIFC_OP_TFP && nlev > 1) // widths the one-launch kernel does not take: the two passes, each over all levels
     return tfp_two_passes(c, nx, ny, f0, xm, ym, out0, fdefined, undef, nlev);
+  if (op == MIFC_OP_QVECTOR && nlev > 1 && tscale && cscale) {
+    if (!ensure_levels(c, (size_t)nlev))
+      return 0;
+    // the three passes (:555-590), each ONE launch over all levels; the last one takes its two scalars per level from
+    // device tables (they depend on the level's pressure)
+    const size_t nb = n * (size_t)nlev;
+    if (!ensure_slot(c, 8, nb * sizeof(float)) || !ensure_slot(c, 9, nb * sizeof(float)))
+      return 0;
+    float* d_ug = static_cast<float*>(c->slot[8]);
+    float* d_vg = static_cast<float*>(c->slot[9]);
+    StencilCall pass1 = {mifc::ST_GWIND_X, nx, ny, nlev, f0, nullptr, xm, ym, fc, d_ug, nullptr};
+    if (!run_stencil(c, pass1, fdefined, undef, MIFC_MEM_DEVICE))
+      return 0;
+    StencilCall pass2 = {mifc::ST_GWIND_Y, nx, ny, nlev, f0, nullptr, xm, ym, fc, d_vg, nullptr};
+    if (!run_stencil(c, pass2, fdefined, undef, MIFC_MEM_DEVICE))
+      return 0;
+    // the tables go up on the stream the passes run on; run_stencil() synchronises before it returns, so the host
+    // vectors outlive the copies
+    MIFC_HIP(c, hipMemcpyAsync(c->d_ab, tscale, sizeof(float) * (size_t)nlev, hipMemcpyHostToDevice, c->stream));
+    MIFC_HIP(c, hipMemcpyAsync(c->d_ab + c->cap_lev, cscale, sizeof(float) * (size_t)nlev, hipMemcpyHostToDevice, c->stream));
+    StencilCall pass3 = {compute < 3 ? mifc::ST_QVEC_X : mifc::ST_QVEC_Y, nx, ny, nlev, d_ug, d_vg, xm, ym, nullptr, out0, nullptr};
+    pass3.f2 = f1;
+    pass3.scale_lev = c->d_ab;
+    pass3.scale2_lev = c->d_ab + c->cap_lev;
+    return run_stencil(c, pass3, fdefined, undef, MIFC_MEM_DEVICE);
+  }
   for (int l = 0; l < nlev; ++l) {
     int rc;
     if (op == MIFC_OP_TFP)
@@ -1471,7 +1502,8 @@ int mifc_stencil_levels_ex(mifc_ctx* c, int op, int nx, int ny, int nlev, const 
     }
   }
   // level by level on the staged (device) batch
-  if (!f1_levels_fallback(c, op, nx, ny, nlev, d0, d1, dxm, dym, dfc, level_scalars, compute, dout, fdefined, undef))
+  if (!f1_levels_fallback(c, op, nx, ny, nlev, d0, d1, dxm, dym, dfc, level_scalars, compute, dout, fdefined, undef,
+                          tscale.empty() ? nullptr : tscale.data(), cscale.empty() ? nullptr : cscale.data()))
     return 0;
   if (!fetch_out(c, 5, out0, nb, memkind))
     return 0;

@@ -231,6 +231,8 @@ struct StencilParams
   const float* f2; // third input (advection: v)
   float scale;     // advection: -3600 * hours, rounded to float like the reference (:1963); Q-vector: tscale
   float scale2;    // Q-vector: c = -r / (p * 100) (:564)
+  const float* scale_lev;  // Q-vector over a level batch: tscale / c per level of the launch (device), or null: scale / scale2
+  const float* scale2_lev;
   const float* xmapr;
   const float* ymapr;
   const float* fcoriolis;

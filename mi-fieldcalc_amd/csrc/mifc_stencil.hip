@@ -113,16 +113,18 @@ __device__ __forceinline__ bool stencil_raw(const StencilParams& P, const float*
           tw != undef && te != undef && tn != undef))
       return false;
     const double hx = 0.5 * (double)P.xmapr[p], hy = 0.5 * (double)P.ymapr[p];
-    const float dtdx = (float)(hx * (double)P.scale * (double)(te - tw));
-    const float dtdy = (float)(hy * (double)P.scale * (double)(tn - ts));
+    const float scale = P.scale_lev ? P.scale_lev[blockIdx.y] : P.scale; // level batch: the pressure differs per level
+    const float scale2 = P.scale2_lev ? P.scale2_lev[blockIdx.y] : P.scale2;
+    const float dtdx = (float)(hx * (double)scale * (double)(te - tw));
+    const float dtdy = (float)(hy * (double)scale * (double)(tn - ts));
     if (OP == ST_QVEC_X) {
       const float dugdx = half_prod(P.xmapr[p], ue - uw);
       const float dvgdx = half_prod(P.xmapr[p], ve - vw);
-      o.o0 = P.scale2 * (dugdx * dtdx + dvgdx * dtdy);
+      o.o0 = scale2 * (dugdx * dtdx + dvgdx * dtdy);
     } else {
       const float dugdy = half_prod(P.ymapr[p], un - us);
       const float dvgdy = half_prod(P.ymapr[p], vn - vs);
-      o.o0 = P.scale2 * (dugdy * dtdx + dvgdy * dtdy);
+      o.o0 = scale2 * (dugdy * dtdx + dvgdy * dtdy);
     }
     return true;
   }
@@ -531,6 +533,8 @@ hipError_t launch_cell(const StencilParams& prm, hipStream_t stream)
     p.out1 = prm.out1 ? prm.out1 + (size_t)l0 * prm.out_level_stride : nullptr;
     p.all_defined = prm.all_defined ? prm.all_defined + l0 : nullptr;
     p.n_undefined = prm.n_undefined ? prm.n_undefined + l0 : nullptr;
+    p.scale_lev = prm.scale_lev ? prm.scale_lev + l0 : nullptr;
+    p.scale2_lev = prm.scale2_lev ? prm.scale2_lev + l0 : nullptr;
     if (prm.every_level_all_defined)
       hipLaunchKernelGGL((stencil_cell_kernel<OP, false>), dim3((unsigned)gx, nl), dim3(block), 0, stream, p);
     else

@@ -58,6 +58,11 @@ def main():
             print("%-10d %-34s %10.4f %10.1f" % (nx, "advection (stencil_levels_ex), ALL", t, n * 16 / t / 1e6 / 80.0))
             t = timed(lambda: ctx.stencil_levels_ex("thermalFrontParameter", du, xmapr=dxm, ymapr=dym, fdefined=flags, out0=rv))
             print("%-10d %-34s %10.4f %10.1f" % (nx, "TFP (stencil_levels_ex), ALL", t, n * 8 / t / 1e6 / 80.0))
+            dfc = torch.from_numpy(fcor).to(dev)
+            plev = np.linspace(1000.0, 100.0, nlev).astype(np.float32)
+            t = timed(lambda: ctx.stencil_levels_ex("plevelqvector", du, dv, xmapr=dxm, ymapr=dym, fcoriolis=dfc, level_scalars=plev, compute=2,
+                                                    fdefined=flags, out0=rv))
+            print("%-10d %-34s %10.4f %10.1f" % (nx, "Q-vector x (stencil_levels_ex), ALL", t, n * 12 / t / 1e6 / 80.0))
             t = timed(lambda: ctx.stencil_levels_ex("shapiro2_filter", du, fdefined=flags, out0=rv))
             print("%-10d %-34s %10.4f %10.1f" % (nx, "shapiro2 (stencil_levels_ex), ALL", t, n * 8 / t / 1e6 / 80.0))
 
