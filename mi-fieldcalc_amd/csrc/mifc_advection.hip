@@ -87,11 +87,11 @@ __global__ __launch_bounds__(256) void advection_oneshot_kernel(const StencilPar
     const float w = fx[k], e = fx[k + 2], s = fs[k], n = fn[k], uc = u4[k], vc = v4[k];
     bool ok = true;
     if (CHECK) // :1971
-      ok = all || (is_def(uc, undef) && is_def(vc, undef) && is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef));
+      ok = all | all_def(undef, uc, vc, s, w, e, n);
     const float r = (float)(((double)uc * 0.5 * (double)xm4[k] * (double)(e - w) + (double)vc * 0.5 * (double)ym4[k] * (double)(n - s)) * (double)P.scale); // :1972
     z[k] = ok ? r : undef;
-    if (CHECK && !ok && act)
-      bad += 1;
+    if (CHECK)
+      bad += (!ok & act) ? 1u : 0u;
   }
   if (col == 0) // fillEdges, column part (:65-68)
     z[0] = z[1];

@@ -41,6 +41,19 @@ __device__ __forceinline__ bool is_def(float x, float undef)
 {
   return !(x != x) && x != undef;
 }
+// "every one of these is defined" as straight-line code: all the compares, combined without short-circuits.  A chain of
+// is_def() && is_def() && ... in front of a conditionally evaluated formula becomes a nest of exec-mask regions and
+// branches per cell (the tested variant of the fused wind kernel ran 11 % behind the untested one that way, 3.5 % now);
+// kernels use this and a select behind the unconditionally computed formula: pick(ok, value, undef).
+template <typename... T>
+__device__ __forceinline__ bool all_def(float undef, T... x)
+{
+  return (is_def(x, undef) & ...);
+}
+__device__ __forceinline__ float pick(bool ok, float value, float undef)
+{
+  return ok ? value : undef;
+}
 
 // ---- saturation vapour pressure table (MetConstants.h:56-84, MetConstants.cc:37-45)
 // The 41-entry table lives in LDS (164 B per workgroup): lookups are per-lane

@@ -127,9 +127,9 @@ template <bool CHECK, bool CANON = false>
 __device__ __forceinline__ float tfp_absdelt(float s, float w, float e, float n, float xm, float ym, float undef, bool& ok)
 {
   if (CANON)
-    ok = !(either_nan(s, w) || either_nan(e, n));
+    ok = !(either_nan(s, w) | either_nan(e, n));
   else
-    ok = !CHECK || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef));
+    ok = !CHECK || all_def(undef, s, w, e, n);
   const float dfdx = half_prod(xm, e - w);
   const float dfdy = half_prod(ym, n - s);
   const float g = absval(dfdx, dfdy);
@@ -142,7 +142,7 @@ __device__ __forceinline__ float tfp_absdelt(float s, float w, float e, float n,
 template <bool CHECK>
 __device__ __forceinline__ void qvec_gwind(float s, float w, float e, float n, float xm, float ym, float fc, float undef, float& ug, float& vg)
 {
-  const bool ok = is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef);
+  const bool ok = all_def(undef, s, w, e, n);
   const double fd = (double)fc, finv = shared_reciprocal(fd);
   const float u = (float)quotient(-0.5 * (double)ym * (double)(n - s) * (double)MIFC_K_G, fd, finv);
   const float v = (float)quotient(0.5 * (double)xm * (double)(e - w) * (double)MIFC_K_G, fd, finv);
@@ -156,12 +156,11 @@ __device__ __forceinline__ float tfp_point(float ts, float tw, float te, float t
 {
   bool def;
   if (CANON)
-    def = !(either_nan(ts, tw) || either_nan(te, tn) || either_nan(gs, gw) || either_nan(ge, gn) || g != g);
+    def = !(either_nan(ts, tw) | either_nan(te, tn) | either_nan(gs, gw) | either_nan(ge, gn) | (g != g));
   else
-    def = !CHECK || (is_def(ts, undef) && is_def(tw, undef) && is_def(te, undef) && is_def(tn, undef) && is_def(gs, undef) && is_def(gw, undef) &&
-                     is_def(g, undef) && is_def(ge, undef) && is_def(gn, undef));
-  ok = def && g != 0;
-  rejected_by_test_only = CHECK && !def && g != 0;
+    def = !CHECK || all_def(undef, ts, tw, te, tn, gs, gw, g, ge, gn);
+  ok = def & (g != 0);
+  rejected_by_test_only = CHECK && (!def & (g != 0));
   const double hx = 0.5 * (double)xm, hy = 0.5 * (double)ym;
   const float dabsdeltdx = half_prod(xm, ge - gw);
   const float dabsdeltdy = half_prod(ym, gn - gs);
@@ -175,8 +174,8 @@ template <int OP>
 __device__ __forceinline__ float qvec_point(float us, float uw, float ue, float un, float vs, float vw, float ve, float vn, float ts, float tw, float te,
                                             float tn, float xm, float ym, float scale, float scale2, float undef, bool& ok)
 {
-  ok = us != undef && uw != undef && ue != undef && un != undef && vs != undef && vw != undef && ve != undef && vn != undef && ts != undef &&
-       tw != undef && te != undef && tn != undef;
+  ok = (us != undef) & (uw != undef) & (ue != undef) & (un != undef) & (vs != undef) & (vw != undef) & (ve != undef) & (vn != undef) & (ts != undef) &
+       (tw != undef) & (te != undef) & (tn != undef);
   const double hx = 0.5 * (double)xm, hy = 0.5 * (double)ym;
   // scale == 1 (compute 1, 3: temperature as it is): the product has two float-born factors again
   const float dtdx = scale == 1.0f ? half_prod(xm, te - tw) : (float)(hx * (double)scale * (double)(te - tw));

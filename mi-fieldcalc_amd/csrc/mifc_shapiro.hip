@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void shapiro2_tile_kernel(const float* __restri
     *reinterpret_cast<float4*>(ringF + slot(rs, RF) * S2_TS + p) = s2_ld4(src + clamp_row(rs));
 
   // is_def of the three cells of a stencil in the unsmoothed field
-  auto def3 = [&](float a, float c, float b) { return is_def(a, undef) && is_def(c, undef) && is_def(b, undef); };
+  auto def3 = [&](float a, float c, float b) { return all_def(undef, a, c, b); };
 
 #pragma unroll 1
   for (int r = rs; r <= re; ++r) {

@@ -185,15 +185,12 @@ template <int OP, bool CHECK>
 __device__ __forceinline__ bool scalar_from_values(bool all, float undef, float s, float w, float c, float e, float n, float xmf, float ymf, float fcf,
                                                    CellOut& o)
 {
+  // straight-line code (all_def()): the formula runs unconditionally, the caller's select discards what undefined inputs made of it
   if (OP == ST_GRAD_Y) { // :2027-2028
-    if (CHECK && !(all || (is_def(s, undef) && is_def(n, undef))))
-      return false;
     o.o0 = half_prod(ymf, n - s);
-    return true;
+    return !CHECK || (all | all_def(undef, s, n));
   }
   if (OP == ST_GRAD_LAP || OP == ST_GVORT) {
-    if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(c, undef) && is_def(e, undef) && is_def(n, undef)))) // :2053, :729
-      return false;
     const double xm = xmf, ym = ymf;
     if (OP == ST_GRAD_LAP) { // :2054-2056, second differences rounded to float first
       const float d2x = (float)((double)w - 2.0 * (double)c + (double)e);
@@ -205,10 +202,8 @@ __device__ __forceinline__ bool scalar_from_values(bool all, float undef, float 
       const double d2y = (double)s - 2. * (double)c + (double)n;
       o.o0 = (float)((0.25 * xm * xm * d2x + 0.25 * ym * ym * d2y) * (double)g4 / (double)fcf);
     }
-    return true;
+    return !CHECK || (all | all_def(undef, s, w, c, e, n)); // :2053, :729
   }
-  if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef)))) // :2039, :660, :693, :1534
-    return false;
   if (OP == ST_GRAD_ABS) { // :2040-2042
     const float dfdx = half_prod(xmf, e - w);
     const float dfdy = half_prod(ymf, n - s);
@@ -222,7 +217,7 @@ __device__ __forceinline__ bool scalar_from_values(bool all, float undef, float 
     o.o0 = (float)(-0.5 * (double)ymf * (double)(n - s) / fc);
     o.o1 = (float)(0.5 * (double)xmf * (double)(e - w) / fc);
   }
-  return true;
+  return !CHECK || (all | all_def(undef, s, w, e, n)); // :2039, :660, :693, :1534
 }
 
 // Final value(s) of owned cell i (flat local index) after fillEdges, and its contribution to the undefined count.
@@ -412,41 +407,35 @@ __global__ __launch_bounds__(256) void wind_flat4_kernel(const StencilParams P, 
         bool ok = true;
         raw[k].o0 = undef;
         raw[k].o1 = undef;
+        // straight-line code (all_def()): formulas unconditional, selects behind them
         if (OP == ST_JACOBIAN) { // :2443-2451: all eight neighbours tested, four float-rounded partials, float combination
           if (CHECK)
-            ok = all || (is_def(us[k], undef) && is_def(uw, undef) && is_def(ue, undef) && is_def(un[k], undef) && is_def(vs[k], undef) && is_def(vw, undef) &&
-                         is_def(ve, undef) && is_def(vn[k], undef));
-          if (ok) {
-            const float df1dx = half_prod(xm4[k], ue - uw);
-            const float df1dy = half_prod(ym4[k], un[k] - us[k]);
-            const float df2dx = half_prod(xm4[k], ve - vw);
-            const float df2dy = half_prod(ym4[k], vn[k] - vs[k]);
-            raw[k].o0 = df1dx * df2dy - df1dy * df2dx;
-          }
+            ok = all | all_def(undef, us[k], uw, ue, un[k], vs[k], vw, ve, vn[k]);
+          const float df1dx = half_prod(xm4[k], ue - uw);
+          const float df1dy = half_prod(ym4[k], un[k] - us[k]);
+          const float df2dx = half_prod(xm4[k], ve - vw);
+          const float df2dy = half_prod(ym4[k], vn[k] - vs[k]);
+          raw[k].o0 = pick(ok, df1dx * df2dy - df1dy * df2dx, undef);
         } else if (WIND) {
           if (CHECK) // :1861 == :1895 == :1927
-            ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef));
-          if (ok) {
-            if (OP == ST_RELVORT)
-              raw[k].o0 = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
-            else if (OP == ST_ABSVORT)
-              raw[k].o0 = f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]);
-            else if (OP == ST_DIVERGENCE)
-              raw[k].o0 = f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]);
-            else {
-              raw[k].o0 = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
-              raw[k].o1 = f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]);
-            }
+            ok = all | all_def(undef, vw, ve, us[k], un[k]);
+          if (OP == ST_RELVORT)
+            raw[k].o0 = pick(ok, f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]), undef);
+          else if (OP == ST_ABSVORT)
+            raw[k].o0 = pick(ok, f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]), undef);
+          else if (OP == ST_DIVERGENCE)
+            raw[k].o0 = pick(ok, f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]), undef);
+          else {
+            raw[k].o0 = pick(ok, f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]), undef);
+            raw[k].o1 = pick(ok, f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]), undef);
           }
         } else {
           ok = scalar_from_values<OP, CHECK>(all, undef, us[k], uw, ucx[k + 1], ue, un[k], xm4[k], ym4[k], fc4[k], raw[k]);
-          if (!ok) {
-            raw[k].o0 = undef;
-            raw[k].o1 = undef;
-          }
+          raw[k].o0 = pick(ok, raw[k].o0, undef);
+          raw[k].o1 = pick(ok, raw[k].o1, undef);
         }
-        if (CHECK && !all && !ok && row_ok[k])
-          bad += 1;
+        if (CHECK)
+          bad += (!all & !ok & row_ok[k]) ? 1u : 0u;
       }
       // fillEdges, column part: column 0 takes the raw value of column 1 (the next flat cell), column nx-1 that of
       // column nx-2 (the previous one) -- from this lane's group or from the adjacent lane's

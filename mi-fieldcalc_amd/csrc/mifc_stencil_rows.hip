@@ -83,21 +83,17 @@ template <int OP, bool CHECK>
 __device__ __forceinline__ bool scalar_cell(bool all, float undef, float w, float c, float e, float s, float n, float xm, float ym, float fc, float& o0,
                                             float& o1)
 {
+  // straight-line code: the tests are combined without short-circuits, the formula runs unconditionally (on undefined
+  // inputs it produces some number, infinity or NaN that the caller's select discards) -- see all_def()
   if (OP == ST_GRAD_X) { // :2015-2016
-    if (CHECK && !(all || (is_def(w, undef) && is_def(e, undef))))
-      return false;
     o0 = half_prod(xm, e - w);
-    return true;
+    return !CHECK || (all | all_def(undef, w, e));
   }
   if (OP == ST_GRAD_Y) { // :2027-2028
-    if (CHECK && !(all || (is_def(s, undef) && is_def(n, undef))))
-      return false;
     o0 = half_prod(ym, n - s);
-    return true;
+    return !CHECK || (all | all_def(undef, s, n));
   }
   if (OP == ST_GRAD_LAP || OP == ST_GVORT) {
-    if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(c, undef) && is_def(e, undef) && is_def(n, undef)))) // :2053, :729
-      return false;
     const double dxm = xm, dym = ym;
     if (OP == ST_GRAD_LAP) { // :2054-2056
       const float d2x = (float)((double)w - 2.0 * (double)c + (double)e);
@@ -109,10 +105,8 @@ __device__ __forceinline__ bool scalar_cell(bool all, float undef, float w, floa
       const double d2y = (double)s - 2. * (double)c + (double)n;
       o0 = (float)((0.25 * dxm * dxm * d2x + 0.25 * dym * dym * d2y) * (double)g4 / (double)fc);
     }
-    return true;
+    return !CHECK || (all | all_def(undef, s, w, c, e, n)); // :2053, :729
   }
-  if (CHECK && !(all || (is_def(s, undef) && is_def(w, undef) && is_def(e, undef) && is_def(n, undef)))) // :2039, :660, :693, :1534
-    return false;
   if (OP == ST_GRAD_ABS) { // :2040-2042
     const float dfdx = half_prod(xm, e - w);
     const float dfdy = half_prod(ym, n - s);
@@ -126,7 +120,7 @@ __device__ __forceinline__ bool scalar_cell(bool all, float undef, float w, floa
     o0 = (float)(-0.5 * (double)ym * (double)(n - s) / dfc);
     o1 = (float)(0.5 * (double)xm * (double)(e - w) / dfc);
   }
-  return true;
+  return !CHECK || (all | all_def(undef, s, w, e, n)); // :2039, :660, :693, :1534
 }
 
 template <int OP, bool CHECK, int V>
@@ -266,8 +260,8 @@ __global__ __launch_bounds__(1024) void scalar_rows_kernel(const SRowsParams P)
           const bool ok = scalar_cell<OP, CHECK>(all, undef, fc6[k], fc6[k + 1], fc6[k + 2], sv, nv, xm4[k], ym4[k], fc4[k], r0, r1);
           z0[k] = ok ? r0 : undef;
           z1[k] = ok ? r1 : undef;
-          if (CHECK && !ok && actq[q])
-            bad += 1;
+          if (CHECK)
+            bad += (!ok & actq[q]) ? 1u : 0u;
         }
         if (colq[q] == 0) { // fillEdges, column part
           z0[0] = z0[1];
@@ -361,8 +355,8 @@ __global__ __launch_bounds__(256) void scalar_oneshot_kernel(const SRowsParams P
     const bool ok = scalar_cell<OP, CHECK>(all, undef, fc6[k], fc6[k + 1], fc6[k + 2], fs[k], fn[k], xm4[k], ym4[k], co4[k], r0, r1);
     z0[k] = ok ? r0 : undef;
     z1[k] = ok ? r1 : undef;
-    if (CHECK && !ok && act)
-      bad += 1;
+    if (CHECK)
+      bad += (!ok & act) ? 1u : 0u;
   }
   if (col == 0) { // fillEdges, column part
     z0[0] = z0[1];
@@ -499,8 +493,8 @@ __global__ __launch_bounds__(64 * LW_WAVES, 6) void scalar_levelwalk_kernel(cons
           const bool ok = scalar_cell<OP, CHECK>(all, undef, fc6[k], fc6[k + 1], fc6[k + 2], fs[k], fn[k], xm4[k], ym4[k], fc4[k], r0, r1);
           z0[k] = ok ? r0 : undef;
           z1[k] = ok ? r1 : undef;
-          if (CHECK && !ok && act)
-            bad += 1;
+          if (CHECK)
+            bad += (!ok & act) ? 1u : 0u;
         }
         if (col == 0) { // fillEdges, column part
           z0[0] = z0[1];
@@ -574,6 +568,25 @@ inline bool a16(const void* p)
 
 // Fast path for whole fields with nx % 4 == 0 and 16-byte aligned pointers;
 // otherwise *handled stays false and the one-lane-per-cell kernel runs.
+// gradient compute 1 (FieldCalculations.cc:2013-2021) tests and counts over the flat cells 1 .. nx*ny-2: rows 0 and ny-1
+// as well (cells 1 .. nx-1 of row 0 and 0 .. nx-2 of row ny-1, with the flat neighbours i-1 / i+1).  Their values are
+// overwritten by fillEdges; their share of the undefined count is added here.  grid.y = level.
+__global__ __launch_bounds__(256) void gradx_outer_rows_count_kernel(const SRowsParams P)
+{
+  const int lev = blockIdx.y;
+  unsigned int bad = 0;
+  if (!(P.all_defined && P.all_defined[lev] != 0)) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int per_row = P.nx - 1;
+    if (t < 2 * per_row) {
+      const long i = t < per_row ? 1 + t : (long)(P.ny - 1) * P.nx + (t - per_row);
+      const float* f = P.f + (size_t)lev * P.in_stride;
+      bad = all_def(P.undef, f[i - 1], f[i + 1]) ? 0u : 1u;
+    }
+  }
+  block_count_add(P.n_undefined + lev, bad);
+}
+
 hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool* handled)
 {
   *handled = false;
@@ -583,10 +596,8 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   const int nx = prm.nx, ny = prm.ny_global;
   if (prm.j0 != 0 || prm.ny_local != ny || nx % 4 != 0 || nx < 8 || ny < 3)
     return hipSuccess;
-  // gradient compute 1 counts over the flat range [1, nx*ny-1), i.e. also in
-  // rows 0 and ny-1 which this kernel does not walk: only its no-test variant is taken
-  if (op == ST_GRAD_X && !prm.every_level_all_defined)
-    return hipSuccess;
+  // gradient compute 1 counts over the flat range [1, nx*ny-1), i.e. also in rows 0 and ny-1, which the row kernels
+  // do not walk: gradx_outer_rows_count_kernel adds those cells' share behind the main launch (values there are fill copies)
   const bool use_xm = (op != ST_GRAD_Y && op != ST_GWIND_X);
   const bool use_ym = (op != ST_GRAD_X && op != ST_GWIND_Y);
   const bool use_fc = (op == ST_GWIND_X || op == ST_GWIND_Y || op == ST_GVORT || op == ST_IGWIND);
@@ -685,6 +696,8 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   switch (op) {
   case ST_GRAD_X:
     launch_op<ST_GRAD_X>(rp, check, form, grid, lds, stream);
+    if (check && rp.n_undefined)
+      hipLaunchKernelGGL(gradx_outer_rows_count_kernel, dim3((unsigned)((2 * (nx - 1) + 255) / 256), (unsigned)prm.nlev), dim3(256), 0, stream, rp);
     break;
   case ST_GRAD_Y:
     launch_op<ST_GRAD_Y>(rp, check, form, grid, lds, stream);

@@ -415,10 +415,9 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
           const float ua = rp.u[q][k], ub = rn.u[q][k], va = rp.v[q][k], vb = rn.v[q][k]; // rows j-1 / j+1 in walk order
           bool ok = true;
           if (CHECK && !JAC)
-            ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(ua, undef) && is_def(ub, undef)); // :1861, :1927
+            ok = all | all_def(undef, vw, ve, ua, ub); // :1861, :1927
           if (CHECK && JAC) // :2443-2444: all eight neighbours
-            ok = all || (is_def(uw, undef) && is_def(ue, undef) && is_def(ua, undef) && is_def(ub, undef) && is_def(vw, undef) && is_def(ve, undef) &&
-                         is_def(va, undef) && is_def(vb, undef));
+            ok = all | all_def(undef, uw, ue, ua, ub, vw, ve, va, vb);
           const float dudy = up ? (ua - ub) : (ub - ua); // u[i+nx] - u[i-nx]
           const float dvdy = up ? (va - vb) : (vb - va);
           zv[k] = 0.f;
@@ -428,13 +427,13 @@ __global__ __launch_bounds__(512) void vortdiv_rows_kernel(const RowsParams P)
             const float df1dy = half_prod(ym4[k], dudy);
             const float df2dx = half_prod(xm4[k], ve - vw);
             const float df2dy = half_prod(ym4[k], dvdy);
-            zv[k] = ok ? (df1dx * df2dy - df1dy * df2dx) : undef;
+            zv[k] = pick(ok, df1dx * df2dy - df1dy * df2dx, undef);
           } else if (WANT_V)
-            zv[k] = ok ? (ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, dudy, fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, dudy)) : undef;
+            zv[k] = pick(ok, ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, dudy, fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, dudy), undef);
           if (WANT_D)
-            zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, dvdy) : undef;
-          if (CHECK && !ok && actq[q])
-            bad += 1;
+            zd[k] = pick(ok, f_diverg(xm4[k], ym4[k], ue - uw, dvdy), undef);
+          if (CHECK)
+            bad += (!ok & actq[q]) ? 1u : 0u;
         }
         // ---- fillEdges, column part (:65-68), folded into the store ----------
         if (colq[q] == 0) {
@@ -554,10 +553,9 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
     const float vw = vcx[k], ve = vcx[k + 2], uw = ucx[k], ue = ucx[k + 2];
     bool ok = true;
     if (CHECK && !JAC)
-      ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef)); // :1861, :1927
+      ok = all | all_def(undef, vw, ve, us[k], un[k]); // :1861, :1927
     if (CHECK && JAC) // :2443-2444: all eight neighbours
-      ok = all || (is_def(uw, undef) && is_def(ue, undef) && is_def(us[k], undef) && is_def(un[k], undef) && is_def(vw, undef) && is_def(ve, undef) &&
-                   is_def(vs[k], undef) && is_def(vn[k], undef));
+      ok = all | all_def(undef, uw, ue, us[k], un[k], vw, ve, vs[k], vn[k]);
     zv[k] = 0.f;
     zd[k] = 0.f;
     if (JAC) { // :2445-2449: four float-rounded partials, float combination (u = field1, v = field2)
@@ -565,13 +563,13 @@ __global__ __launch_bounds__(256) void vortdiv_oneshot_kernel(const RowsParams P
       const float df1dy = half_prod(ym4[k], un[k] - us[k]);
       const float df2dx = half_prod(xm4[k], ve - vw);
       const float df2dy = half_prod(ym4[k], vn[k] - vs[k]);
-      zv[k] = ok ? (df1dx * df2dy - df1dy * df2dx) : undef;
+      zv[k] = pick(ok, df1dx * df2dy - df1dy * df2dx, undef);
     } else if (WANT_V)
-      zv[k] = ok ? (ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k])) : undef;
+      zv[k] = pick(ok, ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]), undef);
     if (WANT_D)
-      zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]) : undef;
-    if (CHECK && !ok && act)
-      bad += 1;
+      zd[k] = pick(ok, f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]), undef);
+    if (CHECK)
+      bad += (!ok & act) ? 1u : 0u;
   }
   if (col == 0) { // fillEdges, column part (:65-68)
     zv[0] = zv[1];
@@ -699,15 +697,15 @@ __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsP
     const float vw = vcx[k], ve = vcx[k + 2], uw = ucx[k], ue = ucx[k + 2];
     bool ok = true;
     if (CHECK)
-      ok = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef)); // :1861, :1927
+      ok = all | all_def(undef, vw, ve, us[k], un[k]); // :1861, :1927
     zv[k] = 0.f;
     zd[k] = 0.f;
     if (WANT_V)
-      zv[k] = ok ? (ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k])) : undef;
+      zv[k] = pick(ok, ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]), undef);
     if (WANT_D)
-      zd[k] = ok ? f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]) : undef;
-    if (CHECK && !ok && act)
-      bad += 1;
+      zd[k] = pick(ok, f_diverg(xm4[k], ym4[k], ue - uw, vn[k] - vs[k]), undef);
+    if (CHECK)
+      bad += (!ok & act) ? 1u : 0u;
   }
   if (col == 0) { // fillEdges, column part (:65-68)
     zv[0] = zv[1];
@@ -958,11 +956,11 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
           for (int k = 0; k < 4; ++k) {
             const float vw = vcx[k], ve = vcx[k + 2];
             if (CHECK) // both operators test these four values (:1861, :1927)
-              ok[k] = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef));
+              ok[k] = all | all_def(undef, vw, ve, us[k], un[k]);
             if (WANT_V)
-              zv[k] = ok[k] ? f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]) : undef;
-            if (CHECK && !ok[k] && act)
-              bad += 1;
+              zv[k] = pick(ok[k], f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]), undef);
+            if (CHECK)
+              bad += (!ok[k] & act) ? 1u : 0u;
           }
           if (WANT_V) {
             if (col == 0) // fillEdges, column part (:65-68)
@@ -996,7 +994,7 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
           float zd[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            zd[k] = ok[k] ? f_diverg(xm4[k], ym4[k], ucx[k + 2] - ucx[k], vn[k] - vs[k]) : undef;
+            zd[k] = pick(ok[k], f_diverg(xm4[k], ym4[k], ucx[k + 2] - ucx[k], vn[k] - vs[k]), undef);
           if (col == 0)
             zd[0] = zd[1];
           if (col + 4 == nx)
@@ -1220,14 +1218,25 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
         const v4f un = srow[buf][slot + 1][0][lane], us = srow[buf][slot - 1][0][lane];
         const float vcx[6] = {vW, vc.x, vc.y, vc.z, vc.w, vE};
         float zv[4];
+        // The tests are straight-line code: every value is tested once (ONE compare: "ordered and different from undef",
+        // which is is_def() for an undef that is not NaN -- the launcher sends a NaN undef to the other kernels), the
+        // results are combined without short-circuits and the formula runs unconditionally with a select behind it.
+        // Written with && and ?: the compiler built a nest of exec-mask regions and branches per cell.
+        bool dvx[6] = {true, true, true, true, true, true};
+        if (CHECK) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k)
+            dvx[k] = __builtin_islessgreater(vcx[k], undef);
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float vw = vcx[k], ve = vcx[k + 2];
           if (CHECK) // both operators test these four values (:1861, :1927)
-            ok[k] = all || (is_def(vw, undef) && is_def(ve, undef) && is_def(us[k], undef) && is_def(un[k], undef));
-          zv[k] = ok[k] ? f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]) : undef;
-          if (CHECK && !ok[k] && act)
-            bad += 1;
+            ok[k] = all | (dvx[k] & dvx[k + 2] & (bool)__builtin_islessgreater(us[k], undef) & (bool)__builtin_islessgreater(un[k], undef));
+          const float z = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
+          zv[k] = ok[k] ? z : undef;
+          if (CHECK)
+            bad += (!ok[k] & act) ? 1u : 0u;
         }
         if (col == 0) // fillEdges, column part (:65-68)
           zv[0] = zv[1];
@@ -1252,8 +1261,10 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
         const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
         float zd[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          zd[k] = ok[k] ? f_diverg(xm4[k], ym4[k], ucx[k + 2] - ucx[k], vn[k] - vs[k]) : undef;
+        for (int k = 0; k < 4; ++k) {
+          const float d = f_diverg(xm4[k], ym4[k], ucx[k + 2] - ucx[k], vn[k] - vs[k]);
+          zd[k] = ok[k] ? d : undef;
+        }
         if (col == 0)
           zd[0] = zd[1];
         if (col + 4 == nx)
@@ -1654,6 +1665,13 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       }
       return hipGetLastError();
     }
+  }
+  if (t.K == 4 && !prm.every_level_all_defined && prm.undef != prm.undef) {
+    // the split-role kernel's tests are ONE compare per value ("ordered and != undef"), which is is_def() only for an
+    // undef that is not NaN: a NaN undef takes the level-walking kernel with the generic test
+    t.K = 3;
+    t.D = 0;
+    t.WPB = 8;
   }
   if (t.K == 3 && !rp.fc && prm.op != ST_JACOBIAN && !(rv && dv)) { // level-walking tiles, one output: the default shape only
     constexpr int NW = 12;

@@ -699,6 +699,33 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc
             assert fo[l] == f_e, (name, l, fo[l], f_e)
 
 
+@pytest.mark.parametrize("nx,ny", [(64, 24), (1440, 37), (260, 9)])
+def test_gradient_x_counts_the_outer_rows(gpu_ctx, oracle, nx, ny):
+    """gradient compute=1 tests and counts over the flat cells 1 .. nx*ny-2 (FieldCalculations.cc:2013-2021): rows 0 and ny-1
+    too, whose values fillEdges overwrites.  Levels whose ONLY undefined inputs touch those rows must still come back
+    SOME_DEFINED (the row kernels do not walk them: a small count kernel behind the launch does), a clean level ALL_DEFINED."""
+    import mi_fieldcalc_amd.synth as synth
+
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    spots = [None, (0, 5), (ny - 1, 0), (1, 0), (0, 0), (ny - 1, nx - 1), (0, nx - 1), (ny - 1, nx - 2)]
+    z = np.stack([synth.scalar_field(nx, ny, 40 + l) for l in range(len(spots))])
+    for l, sp in enumerate(spots):
+        if sp is not None:
+            z[l][sp] = cases.UNDEF
+    flags = np.full(len(spots), SOME, np.int32)
+    res = gpu_ctx.stencil_levels("gradient1", z, None, xm, ym, None, fdefined=flags)
+    assert res is not None
+    (o0, _), fo = res
+    for l in range(len(spots)):
+        ok, e, f_e = oracle.call("gradient", nx, ny, z[l], xm, ym, 1, fdefined=SOME)
+        assert ok and cases.same_bits(o0[l], e, nan_payload=False), l
+        assert fo[l] == f_e, (l, spots[l], fo[l], f_e)
+        # and the single-field call
+        got = gpu_ctx.gradient(z[l], xm, ym, 1, fdefined=SOME)
+        assert got is not None and cases.same_bits(got[0], e, nan_payload=False) and got[1] == f_e, (l, spots[l], got[1], f_e)
+    assert fo[0] == ALL and all(f == SOME for f in fo[1:]), fo
+
+
 # ------------------------------------------------------------------ fused stencil-of-a-stencil kernels (mifc_fused2.hip)
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("device", [False, True])
