@@ -14,6 +14,7 @@ struct Env
   bool host_pipeline = true;      // MIFC_HOST_PIPELINE=0: stage host-resident level batches whole
   bool fused2 = true;             // MIFC_FUSED2=0: multi-pass thermalFrontParameter / plevelqvector
   bool shapiro_fused = true;      // MIFC_SHAPIRO_FUSED=0: four-launch shapiro2_filter
+  bool shapiro_regs = true;       // MIFC_SHAPIRO_REGS=0: the one-launch form with its rows in LDS rings instead of registers
   int ewise_max_blocks = 0;       // MIFC_EWISE_MAX_BLOCKS (> 0 overrides the grid cap of the table kernels)
   int scalar_rows_r = -1;         // MIFC_SCALAR_ROWS_R: -1 unset, 0 = "set, keep the default height", > 0 band height
   int fused2_band = 0;            // MIFC_FUSED2_BAND (> 0 overrides the band height of the fused two-stage kernels)

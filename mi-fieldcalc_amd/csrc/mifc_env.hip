@@ -39,6 +39,7 @@ void env_reload()
   e.host_pipeline = not_zero("MIFC_HOST_PIPELINE");
   e.fused2 = not_zero("MIFC_FUSED2");
   e.shapiro_fused = not_zero("MIFC_SHAPIRO_FUSED");
+  e.shapiro_regs = not_zero("MIFC_SHAPIRO_REGS");
   e.ewise_max_blocks = positive_int("MIFC_EWISE_MAX_BLOCKS");
   if (const char* s = std::getenv("MIFC_SCALAR_ROWS_R")) {
     const int v = std::atoi(s);

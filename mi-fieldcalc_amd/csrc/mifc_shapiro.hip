@@ -118,8 +118,13 @@ __device__ __forceinline__ void s2_row6(const float* row, int p, float (&v)[6])
 template <bool ALL>
 __device__ __forceinline__ float s2_update(float c, float a, float b, float s, bool weighted)
 {
-  if (ALL) // :2115, :2123
-    return (float)((double)c + (double)s * ((double)(a + b) - 2. * (double)c));
+  if (ALL) { // :2115, :2123: (float)(c + s * ((a + b) - 2. * c)) in double.  2. * c is exact, so the inner difference is ONE rounding:
+    // fma(-2, c, a + b); s is +-0.25 (a power of two: s * t is exact), so the outer sum is ONE rounding: fma(s, t, c).
+    // Two f64 instructions instead of four (the library is built with -ffp-contract=off).
+    const double cd = (double)c;
+    const double t = __builtin_fma(-2.0, cd, (double)(a + b));
+    return (float)__builtin_fma((double)s, t, cd);
+  }
   return c + (weighted ? 0.25f : 0.f) * (a + b - 2 * c); // :2152, :2160
 }
 
@@ -252,6 +257,110 @@ __global__ __launch_bounds__(64) void shapiro2_tile_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same four sweeps with NOTHING in LDS: a wave owns 240 columns (60 float4 column groups, lanes 0 and 61 hold the
+// halo groups; tiles start 960 B apart: whole 64-B pieces) and walks down its band; the x-neighbours of a row come from the adjacent lanes (DPP wave shifts), the
+// rows above and below from the wave's own registers of the two previous iterations.  Per iteration r:
+//   A(r)   = x sweep of F(r)                                     (F(r) was requested two iterations ago)
+//   B(r-1) = y sweep of A(r-2), A(r-1), A(r)    C(r-1) = x sweep of B(r-1)
+//   D(r-2) = y sweep of C(r-3), C(r-2), C(r-1)  -> stored
+// Why: no LDS instructions, no LDS address arithmetic, no bank conflicts (the unaligned x-neighbour dwords of the ring
+// rows), 8 waves per SIMD instead of 13 per CU, two rows in flight per wave instead of one.  The three-row windows rotate by unrolling the row loop three times (a register move of a row
+// that is still in flight would wait for it).  The tested variant carries, instead of the unsmoothed rows, their
+// is_def bits (4 per lane and row): the x-triple mask of rows r and r-1, the row masks of rows r-3..r.
+template <bool ALL>
+__global__ __launch_bounds__(64, 8) void shapiro2_regs_kernel(const float* __restrict__ src0, float* __restrict__ dst0, const int nx, const int ny,
+                                                              const float undef, const int band, const int ntiles, const long level_stride,
+                                                              const int* __restrict__ levels)
+{
+  constexpr int TW = 240;
+  const size_t level_off = (size_t)(levels ? levels[blockIdx.y] : (int)blockIdx.y) * (size_t)level_stride;
+  const float* __restrict__ src = src0 + level_off;
+  float* __restrict__ dst = dst0 + level_off;
+  const int lane = threadIdx.x;
+  const int tile = (int)blockIdx.x % ntiles;
+  const int bidx = (int)blockIdx.x / ntiles;
+  const int xq = tile * TW - 4 + 4 * lane;
+  const bool infield = xq >= 0 && xq < nx;
+  const bool owned = infield && lane >= 1 && lane <= TW / 4;
+  const bool first_col = xq == 0, last_col = xq + 4 == nx; // the group holds column 0 / nx-1: the x sweeps keep them
+  const int xc = infield ? xq : (xq < 0 ? 0 : nx - 4);     // lanes outside the field load a valid address and use nothing
+  const int jb0 = bidx * band;                               // output rows [jb0, jb1)
+  const int jb1 = (jb0 + band < ny) ? jb0 + band : ny;
+  const int rs = jb0 - 2, re = jb1 + 1;
+  auto row_at = [&](int r) { return *reinterpret_cast<const v4f*>(src + (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + xc); };
+  auto west_of = [](float keep, float x) { // lane i <- lane i-1 (lane 0 keeps `keep`); every lane is active where these run
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
+  };
+  auto east_of = [](float keep, float x) { // lane i <- lane i+1 (lane 63 keeps `keep`)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+  };
+  // x sweep of a row: q = the lane's four cells, m = weights (tested variant: bit k = the x triple of cell k is defined)
+  auto xsweep = [&](const v4f q, const float s, const unsigned m) {
+    const float v[6] = {west_of(q.x, q.w), q.x, q.y, q.z, q.w, east_of(q.w, q.x)};
+    v4f o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = s2_update<ALL>(v[k + 1], v[k], v[k + 2], s, ALL || ((m >> k) & 1u) != 0);
+    if (first_col)
+      o.x = q.x;
+    if (last_col)
+      o.w = q.w;
+    return o;
+  };
+  auto ysweep = [&](const v4f c, const v4f sth, const v4f nth, const float s, const unsigned m) {
+    v4f o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      o[k] = s2_update<ALL>(c[k], sth[k], nth[k], s, ALL || ((m >> k) & 1u) != 0);
+    return o;
+  };
+  const v4f zero = {0.f, 0.f, 0.f, 0.f};
+  v4f F0 = row_at(rs), F1 = row_at(rs + 1), F2 = zero;
+  v4f A0 = zero, A1 = zero, A2 = zero, C0 = zero, C1 = zero, C2 = zero;
+  // tested variant: is_def bits of the unsmoothed rows r, r-1, r-2, r-3 (own cells) and the x-triple masks of rows r, r-1.
+  // (Kept as packed bits in a VGPR: as 24 loop-carried flags -- lane masks combined on the scalar unit -- the compiler
+  // spilled and the variant ran 0.42 instead of 0.285 ms.)
+  unsigned d0 = 0, d1 = 0, d2 = 0, d3 = 0, mx0 = 0, mx1 = 0;
+
+  // one iteration; f_use holds F(r), f_load receives F(r+2); a_new / c_new are the window slots that fall free
+  auto step = [&](const int r, const v4f& f_use, v4f& f_load, v4f& a_new, const v4f& a_c, const v4f& a_s, v4f& c_new, const v4f& c_c, const v4f& c_s)
+                  __attribute__((always_inline)) {
+    f_load = row_at(r + 2);
+    const v4f f = f_use;
+    if (!ALL) {
+      d3 = d2;
+      d2 = d1;
+      d1 = d0;
+      mx1 = mx0;
+      const float fw = west_of(f.x, f.w), fe = east_of(f.w, f.x);
+      const bool df[6] = {is_def(fw, undef), is_def(f.x, undef), is_def(f.y, undef), is_def(f.z, undef), is_def(f.w, undef), is_def(fe, undef)};
+      d0 = (df[1] ? 1u : 0u) | (df[2] ? 2u : 0u) | (df[3] ? 4u : 0u) | (df[4] ? 8u : 0u);
+      mx0 = ((df[0] & df[1] & df[2]) ? 1u : 0u) | ((df[1] & df[2] & df[3]) ? 2u : 0u) | ((df[2] & df[3] & df[4]) ? 4u : 0u) |
+            ((df[3] & df[4] & df[5]) ? 8u : 0u);
+    }
+    // sweep 1 (x, s = 0.25): A(r)
+    a_new = xsweep(f, 0.25f, mx0);
+    // sweep 2 (y): B(r-1); rows 0 and ny-1 pass through (:2125-2128); then sweep 3 (x; -0.25, or the same weights again): C(r-1)
+    const int y = r - 1;
+    const v4f b = (y >= 1 && y <= ny - 2) ? ysweep(a_c, a_s, a_new, 0.25f, d2 & d1 & d0) : a_c;
+    c_new = xsweep(b, -0.25f, mx1);
+    // sweep 4 (y): D(r-2)
+    const int j = r - 2;
+    const v4f d = (j >= 1 && j <= ny - 2) ? ysweep(c_c, c_s, c_new, -0.25f, d3 & d2 & d1) : c_c;
+    if (owned && j >= jb0 && j < jb1)
+      __builtin_nontemporal_store(d, reinterpret_cast<v4f*>(dst + (size_t)j * nx + xq));
+  };
+#pragma unroll 1
+  for (int r = rs; r <= re; r += 3) {
+    step(r, F0, F2, A0, A2, A1, C0, C2, C1);
+    if (r + 1 <= re)
+      step(r + 1, F1, F0, A1, A0, A2, C1, C0, C2);
+    if (r + 2 <= re)
+      step(r + 2, F2, F1, A2, A1, A0, C2, C1, C0);
+  }
+}
+
 } // namespace
 
 bool shapiro2_fused_supported(int nx, int ny, const float* src, const float* dst)
@@ -271,6 +380,24 @@ hipError_t launch_shapiro2_fused_levels(int nx, int ny, int all_defined, float u
     return hipSuccess;
   if (n_launch_levels > 65535)
     return hipErrorInvalidValue;
+  if (env().shapiro_regs) { // the register-resident form: 8 waves per SIMD, bands for about two rounds of the chip
+    const int ntiles = (nx + 239) / 240;
+    // three rounds of the chip's 8192 wave slots: 24-row bands for 1440 x 720 x 137 (0.256 ms; 36 rows 0.264, 48 rows 0.265)
+    const long waves_wanted = env().fused2_band > 0 ? 0 : 256L * 4 * 8 * 3 - 256;
+    const long want_bands = (waves_wanted + (long)ntiles * n_launch_levels - 1) / ((long)ntiles * n_launch_levels);
+    int band = env().fused2_band > 0 ? env().fused2_band : (int)((ny + (want_bands > 0 ? want_bands : 1) - 1) / (want_bands > 0 ? want_bands : 1));
+    if (band < 4)
+      band = 4;
+    if (band > 128)
+      band = 128;
+    const int nbands = (ny + band - 1) / band;
+    const dim3 grid((unsigned)(nbands * ntiles), (unsigned)n_launch_levels);
+    if (all_defined)
+      hipLaunchKernelGGL((shapiro2_regs_kernel<true>), grid, dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles, level_stride, levels);
+    else
+      hipLaunchKernelGGL((shapiro2_regs_kernel<false>), grid, dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles, level_stride, levels);
+    return hipGetLastError();
+  }
   const int ntiles = (nx + S2_TW - 1) / S2_TW;
   const long want_bands = (256L * 12 * 4 + (long)ntiles * n_launch_levels - 1) / ((long)ntiles * n_launch_levels);
   int band = (int)((ny + want_bands - 1) / want_bands);

@@ -76,7 +76,10 @@ def main():
     print("%dx%dx%d, clean data; ms per call (median of %d x %d), %% of 8 TB/s on the algorithmic bytes" % (NX, NY, nlev, ROUNDS, INNER))
     print("%-30s %10s %8s %10s %8s %8s" % ("operator", "ALL ms", "%", "tested ms", "%", "ratio"))
     a_ops, s_ops = ops(all_flags, None), ops(some_flags, cnt)
+    only = os.environ.get("BENCH_ONLY")  # substring of the operator name
     for (name, bpc, fa), (_, _, fs) in zip(a_ops, s_ops):
+        if only and only not in name:
+            continue
         try:
             ta = timed(lambda: fa())
             ts = timed(lambda: fs())
