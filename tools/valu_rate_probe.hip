@@ -22,7 +22,8 @@ constexpr int TRIPS = 2000;
 constexpr int CHAINS = 8;
 constexpr int UNROLL = 8;
 
-enum Op { ADD_F32, PK_ADD_F32, ADD_F64, MUL_F64, FMA_F64, LDEXP_F64, CVT_F64_F32, CVT_F32_F64, RCP_F64, SQRT_F32, RCP_F32, CNDMASK, FMA_F32, DIV_FIXUP_F64 };
+enum Op { ADD_F32, PK_ADD_F32, ADD_F64, MUL_F64, FMA_F64, LDEXP_F64, CVT_F64_F32, CVT_F32_F64, RCP_F64, SQRT_F32, RCP_F32, CNDMASK, FMA_F32, DIV_FIXUP_F64,
+          CNDMASK_SGPR, CNDMASK_3REG, CMP_VCC, CMP_SGPR, CMP_THEN_CNDMASK, MOV, MOV_DPP, BFI, MAX_F32, PK_MUL_F32, PK_FMA_F32, CMP_CLASS };
 
 template <int OP>
 __global__ __launch_bounds__(256) void probe(float* out, float seed)
@@ -66,6 +67,30 @@ __global__ __launch_bounds__(256) void probe(float* out, float seed)
           asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(f[k]));
         else if (OP == DIV_FIXUP_F64)
           asm volatile("v_div_fixup_f64 %0, %0, %0, %0" : "+v"(d[k]));
+        else if (OP == CNDMASK_SGPR)
+          asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(f[k]) : "v"(f[(k + 1) % CHAINS]) : "s20", "s21");
+        else if (OP == CNDMASK_3REG)
+          asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(f[k]) : "v"(f[(k + 1) % CHAINS]), "v"(f[(k + 2) % CHAINS]) : "vcc");
+        else if (OP == CMP_VCC)
+          asm volatile("v_cmp_gt_f32 vcc, %0, %1" : : "v"(f[k]), "v"(f[(k + 1) % CHAINS]) : "vcc");
+        else if (OP == CMP_SGPR)
+          asm volatile("v_cmp_gt_f32_e64 s[20:21], %0, %1" : : "v"(f[k]), "v"(f[(k + 1) % CHAINS]) : "s20", "s21");
+        else if (OP == CMP_THEN_CNDMASK)
+          asm volatile("v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(f[k]) : "v"(f[(k + 1) % CHAINS]) : "vcc");
+        else if (OP == MOV)
+          asm volatile("v_mov_b32 %0, %1" : "=v"(f[k]) : "v"(f[(k + 1) % CHAINS]));
+        else if (OP == MOV_DPP)
+          asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(f[k]) : "v"(f[(k + 1) % CHAINS]));
+        else if (OP == BFI)
+          asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(f[k]) : "v"(f[(k + 1) % CHAINS]), "v"(f[(k + 2) % CHAINS]));
+        else if (OP == MAX_F32)
+          asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[k]) : "v"(f[(k + 1) % CHAINS]));
+        else if (OP == PK_MUL_F32)
+          asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(d[k]));
+        else if (OP == PK_FMA_F32)
+          asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(d[k]));
+        else if (OP == CMP_CLASS)
+          asm volatile("v_cmp_class_f32 vcc, %0, %1" : : "v"(f[k]), "v"(f[(k + 1) % CHAINS]) : "vcc");
       }
     }
   }
@@ -117,6 +142,18 @@ int main()
   run<DIV_FIXUP_F64>("v_div_fixup_f64", out, base);
   run<CVT_F64_F32>("v_cvt_f64_f32", out, base);
   run<CVT_F32_F64>("v_cvt_f32_f64", out, base);
+  run<CNDMASK_3REG>("cndmask 3 regs", out, base);
+  run<CNDMASK_SGPR>("cndmask sgpr", out, base);
+  run<CMP_VCC>("v_cmp vcc", out, base);
+  run<CMP_SGPR>("v_cmp sgpr pair", out, base);
+  run<CMP_CLASS>("v_cmp_class vcc", out, base);
+  run<CMP_THEN_CNDMASK>("cmp+cndmask (2)", out, base);
+  run<MOV>("v_mov_b32", out, base);
+  run<MOV_DPP>("v_mov_b32_dpp", out, base);
+  run<BFI>("v_bfi_b32", out, base);
+  run<MAX_F32>("v_max_f32", out, base);
+  run<PK_MUL_F32>("v_pk_mul_f32", out, base);
+  run<PK_FMA_F32>("v_pk_fma_f32", out, base);
   run<RCP_F64>("v_rcp_f64", out, base);
   run<RCP_F32>("v_rcp_f32", out, base);
   run<SQRT_F32>("v_sqrt_f32", out, base);
