@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--placement-pool", type=int, default=48,
                     help="the four arrays of the batch are chosen from a pool of this many arrays allocated in one go (mi-fieldcalc_amd/placement.py: which "
                          "combination of arrays a kernel streams decides its time by up to 12 %%); 0 = four allocations as they come")
+    ap.add_argument("--placement-rounds", type=int, default=3, help="pools searched one after the other (each of --placement-pool arrays, --placement-tries probes); the best set is kept")
     ap.add_argument("--placement-tries", type=int, default=240, help="probes (index sets of the pool timed with the kernel) the search may spend; the fastest set is kept")
     ap.add_argument("--level-stride", type=int, default=None, help="floats between levels (default: the library's mifc_batch_level_stride)")
     args = ap.parse_args()
@@ -285,10 +286,12 @@ def main():
     # set at all (profiles/r02/experiments/placement_pools.txt), two stretches make that a 3 % event.  Outside every timed region; the report (incl. what the first four arrays of the pool --
     # "allocated in one go" -- would have given) goes into the JSON line.  --placement-pool 0: four allocations as they come.
     warmed = []
-    from mi_fieldcalc_amd.placement import choose_search
+    from mi_fieldcalc_amd.placement import choose_search_rounds
     if args.placement_pool >= 4:
-        (du, dv, rv, dg), placement = choose_search(lambda: ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride), 4, probe_batch,
-                                                    pool_size=args.placement_pool, random_sets=48, max_probes=max(1, args.placement_tries), device=dev)
+        # ... and a pool of 48 can still hold none (two of five processes of one round-end run): up to three pools, the best set kept
+        (du, dv, rv, dg), placement = choose_search_rounds(lambda: ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride), 4, probe_batch,
+                                                           rounds=args.placement_rounds, pool_size=args.placement_pool, random_sets=48,
+                                                           max_probes=max(1, args.placement_tries), device=dev)
     else:
         du, dv, rv, dg = (ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride) for _ in range(4))
         placement = {"method": "four allocations as they come"}

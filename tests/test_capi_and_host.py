@@ -419,6 +419,28 @@ def test_choose_search_finds_the_fast_combination():
         choose_search(allocate, 4, probe, pool_size=3)
 
 
+def test_choose_search_rounds_takes_the_best_pool():
+    """placement.choose_search_rounds: a pool can hold no fast set at all; the next pool comes from OTHER memory (the freed part
+    of the previous one is re-occupied by ballast while it is searched) and the best set over all pools is returned."""
+    from mi_fieldcalc_amd.placement import choose_search_rounds
+
+    made = []
+
+    def allocate():  # "addresses": consecutive numbers; nothing is ever handed out twice while it is held
+        made.append(len(made))
+        return made[-1]
+
+    def probe(arrays):  # only arrays of the SECOND pool's range can form the fast set
+        fast = all(32 <= a < 48 for a in arrays) and sum(arrays) % 2 == 0
+        return 0.38 if fast else 0.41
+
+    chosen, report = choose_search_rounds(allocate, 4, probe, rounds=3, pool_size=16, random_sets=8, max_probes=60)
+    # 16 (pool 1) + 12 (ballast) + 16 (pool 2) + 12 (ballast) + 16 (pool 3)
+    assert len(made) == 72
+    assert report["rounds_chosen_ms"] == [0.41, 0.38, 0.41] and report["chosen_ms"] == 0.38
+    assert all(32 <= a < 48 for a in chosen) and "best of 3 pools" in report["method"]
+
+
 def test_saturation_table_image_is_current():
     """csrc/mifc_ewt_image.h (the LDS image the kernels copy per workgroup) is what tools/gen_ewt_image.py generates
     from the reference's table (MetConstants.h:57-59), and its reciprocals are those of the FLOAT bin widths."""

@@ -70,12 +70,16 @@ def test_scalar_row_kernels_band_heights(gpu_ctx, oracle, rows, mifc_env):
             _check_case(gpu_ctx, oracle, case, device=True)
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fused", ["1", "0", "lds", "band5"])
 def test_shapiro_filter_one_launch_and_four(gpu_ctx, oracle, fused, mifc_env):
-    """The four sweeps in one launch (tiles of 240 columns, bands of rows) == the sweep-by-sweep path == the reference."""
+    """The four sweeps in one launch (tiles of 240 columns, bands of rows; rows in registers, or -- "lds" -- in LDS rings)
+    == the sweep-by-sweep path == the reference.  "band5": the register kernel with 5-row bands, so that every band
+    boundary phase of its three-times-unrolled row loop occurs."""
     import mi_fieldcalc_amd.synth as synth
 
-    mifc_env("MIFC_SHAPIRO_FUSED", fused)
+    mifc_env("MIFC_SHAPIRO_FUSED", "0" if fused == "0" else "1")
+    mifc_env("MIFC_SHAPIRO_REGS", "0" if fused == "lds" else "1")
+    mifc_env("MIFC_FUSED2_BAND", "5" if fused == "band5" else None)
     for nx, ny in [(4, 3), (8, 5), (236, 7), (240, 9), (244, 12), (484, 5), (128, 301), (1440, 37), (5000, 4)]:
         z = synth.scalar_field(nx, ny, 3 * nx + ny)
         for mode in cases.MODES:
