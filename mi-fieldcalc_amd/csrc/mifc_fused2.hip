@@ -38,6 +38,11 @@
 // memory.  (TFP with an ALL_DEFINED input needs no wrapped neighbour for the
 // count -- only |grad| != 0 -- and has no such workgroups.)
 //
+// (A register-resident form like shapiro2_regs_kernel -- x-neighbours by DPP, three-row windows in registers, the first
+// stage's differences carried to the second, no LDS -- was built for thermalFrontParameter at the end of round 2:
+// bit-identical, 22 % fewer instructions per row, but 126 VGPRs = 4 waves per SIMD instead of 5, and no faster
+// (0.472-0.482 against 0.465 ms, tested 0.60 against 0.58: profiles/r02/experiments/tfp_registers.txt).  Not kept.)
+//
 // Requirements (fused2_supported): nx % 4 == 0 and 16-byte aligned fields.
 // Everything else takes the multi-pass path.
 #include <cstdlib>
@@ -119,6 +124,12 @@ __device__ __forceinline__ bool either_nan(float a, float b)
 {
   return __builtin_isunordered(a, b);
 }
+// "any of these" without short-circuits (straight-line code, see all_def() in mifc_device.h)
+template <typename... B>
+__device__ __forceinline__ bool any_of(B... b)
+{
+  return ((b ? 1 : 0) | ...) != 0;
+}
 
 // ---- the point formulas, shared with the edge-count kernel
 // gradient compute 3, FieldCalculations.cc:2037-2046
@@ -127,7 +138,7 @@ template <bool CHECK, bool CANON = false>
 __device__ __forceinline__ float tfp_absdelt(float s, float w, float e, float n, float xm, float ym, float undef, bool& ok)
 {
   if (CANON)
-    ok = !(either_nan(s, w) | either_nan(e, n));
+    ok = !any_of(either_nan(s, w), either_nan(e, n));
   else
     ok = !CHECK || all_def(undef, s, w, e, n);
   const float dfdx = half_prod(xm, e - w);
@@ -156,7 +167,7 @@ __device__ __forceinline__ float tfp_point(float ts, float tw, float te, float t
 {
   bool def;
   if (CANON)
-    def = !(either_nan(ts, tw) | either_nan(te, tn) | either_nan(gs, gw) | either_nan(ge, gn) | (g != g));
+    def = !any_of(either_nan(ts, tw), either_nan(te, tn), either_nan(gs, gw), either_nan(ge, gn), g != g);
   else
     def = !CHECK || all_def(undef, ts, tw, te, tn, gs, gw, g, ge, gn);
   ok = def & (g != 0);
@@ -167,7 +178,7 @@ __device__ __forceinline__ float tfp_point(float ts, float tw, float te, float t
   const double gd = (double)g, ginv = shared_reciprocal(gd);
   const float dtdxa = (float)quotient(hx * (double)(te - tw), gd, ginv);
   const float dtdya = (float)quotient(hy * (double)(tn - ts), gd, ginv);
-  return ok ? -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya) : undef;
+  return pick(ok, -(dabsdeltdx * dtdxa + dabsdeltdy * dtdya), undef); // unconditional arithmetic + select, no branch per cell
 }
 // plevelqvector :570-584, "!= undef" only
 template <int OP>
