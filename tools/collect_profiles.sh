@@ -22,5 +22,6 @@ for d in "$P"/pmc_*/; do
   [ -n "$f" ] && { head -1 "$f"; grep vortdiv "$f" | head -400; } > "$O/$n.csv"
 done
 cp "$D"/summary.txt "$O"/derived_kernel_pmc.txt
+[ -f "$E"/tested_variants.txt ] && cp "$E"/tested_variants.txt "$O"/tested_variants.txt
 [ -f gpurun_out/strict_tolerance_report.txt ] && cp gpurun_out/strict_tolerance_report.txt "$O"/strict_tolerance_report.txt
 ls -la "$O" | head -40

@@ -12,9 +12,9 @@ cat "$O/box.txt"
 python3 bench.py --steps 20 --warmup 5 > "$O/bench_n1.json" 2> "$O/bench_n1.err"
 echo "bench rc=$?"; cat "$O/bench_n1.json"
 echo "# five consecutive processes of 'python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline' on ONE box, same binary" > "$O/bench_repeat.txt"
-echo "# Mcells/s  ms_per_step(wall)  kernel_ms_avg(HIP events)  roofline.frac  tested-variant frac  verified" >> "$O/bench_repeat.txt"
+echo "# Mcells/s  ms_per_step(wall)  kernel_ms_avg(HIP events)  roofline.frac  tested-variant frac  verified  chosen ms per placement pool" >> "$O/bench_repeat.txt"
 for i in 1 2 3 4 5; do
-  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'], d.get('check_variant',{}).get('roofline_frac'), d['verified'])" >> "$O/bench_repeat.txt"
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'], d.get('check_variant',{}).get('roofline_frac'), d['verified'], d['config']['placement'].get('rounds_chosen_ms'))" >> "$O/bench_repeat.txt"
 done
 cat "$O/bench_repeat.txt"
 W="K=3,RB=12,LG=6,ZZ=1,D=0"   # the level-walking kernel whose waves load and store (MIFC_VORTDIV_SPLIT=0); the measurement knobs exist for it
@@ -31,6 +31,8 @@ python3 tools/bench_f1_levels.py 137 > "$O/bench_f1_levels.txt" 2>&1
 echo "f1 rc=$?"
 python3 tools/bench_ops.py 137 > "$O/per_operator_table.txt" 2>&1
 echo "ops rc=$?"
+python3 tools/tested_variants.py 137 > "$O/tested_variants.txt" 2>&1
+echo "tested variants rc=$?"
 python3 tools/bench_hostpath.py > "$O/hostpath.jsonl" 2>&1
 echo "hostpath rc=$?"
 python3 tools/bench_configs.py > "$O/other_configs.jsonl" 2>&1
