@@ -403,11 +403,17 @@ __global__ __launch_bounds__(64 * LW_WAVES, 6) void scalar_levelwalk_kernel(cons
   constexpr bool USE_FC = (OP == ST_GWIND_X || OP == ST_GWIND_Y || OP == ST_GVORT || OP == ST_IGWIND);
   constexpr bool TWO_OUT = (OP == ST_IGWIND);
   __shared__ v4f sf[2][LW_WAVES][64];
+  // undefined counts of a level: the waves add theirs up in LDS, thread 0 (a halo wave) hands the total of level l to the
+  // global counter after the barrier of level l + 1 -- ONE global atomic per workgroup and level (with
+  // one per wave a masked field queued 4 320 same-address atomics per level)
+  __shared__ unsigned int sbad[2];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bid = blockIdx.x;
   const int seq = (bid & 7) * P.per_xcd + (bid >> 3);
   if (seq >= P.n_logical)
     return;
+  if (CHECK && threadIdx.x < 2)
+    sbad[threadIdx.x] = 0; // ordered before the first add by the barrier of the first level
   // unit = (level chunk, row block, column segment), column segment fastest
   const int ntiles = P.uB * P.uW;
   const int lchunk = seq / ntiles;
@@ -476,6 +482,14 @@ __global__ __launch_bounds__(64 * LW_WAVES, 6) void scalar_levelwalk_kernel(cons
       // only the LDS counter is waited for: the prefetch above and earlier stores stay in flight.  Two buffers: a
       // wave can overwrite buffer b again only after the barrier of the level in between.
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (CHECK && P.n_undefined && threadIdx.x == 0 && lev > lev0) { // the previous level's adds are complete
+        const int q = (lev - 1 - lev0) & 1;
+        const unsigned int n = sbad[q];
+        if (n != 0) {
+          atomicAdd(P.n_undefined + (lev - 1), (u64)n);
+          sbad[q] = 0; // the next adds into this slot come after the next barrier
+        }
+      }
       if (computes) {
         const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
         const v4f fn = sf[buf][wave + 1][lane], fs = sf[buf][wave - 1][lane];
@@ -520,12 +534,23 @@ __global__ __launch_bounds__(64 * LW_WAVES, 6) void scalar_levelwalk_kernel(cons
               st4_stream(o1p + oo + nx, z1);
           }
         }
-        if (CHECK && P.n_undefined && !all)
-          wave_count_add(P.n_undefined + lev, bad);
+        if (CHECK && P.n_undefined && !all && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+          const unsigned int n = wave_sum(bad);
+          if (lane == 0)
+            atomicAdd(&sbad[(lev - lev0) & 1], n);
+        }
       }
     }
   }
 chunk_done:;
+  if (CHECK) { // the last level's count
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (P.n_undefined && threadIdx.x == 0 && lev1 > lev0) {
+      const unsigned int n = sbad[(lev1 - 1 - lev0) & 1];
+      if (n != 0)
+        atomicAdd(P.n_undefined + (lev1 - 1), (u64)n);
+    }
+  }
 }
 
 template <int OP>

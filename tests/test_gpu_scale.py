@@ -736,6 +736,38 @@ def test_masked_level_batch_counts(gpu_ctx, oracle, mifc_env):
                 assert _bits_equal(rv[l].cpu().numpy(), rv_e) and _bits_equal(dg[l].cpu().numpy(), dv_e)
 
 
+def test_masked_gradient_level_batch_counts(gpu_ctx, oracle):
+    """Deep batches of gradient compute 1 / 2 run on the scalar level-walking kernel, which adds a level's undefined counts up
+    in LDS and hands one total per workgroup and level to the counter (a masked field used to queue 4 320 same-address
+    atomics per level).  Flags of every level (clean, masked, without any defined value) and values of sampled levels
+    equal the reference's."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 1440, 720, 13
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    z = np.stack([synth.scalar_field(nx, ny, 300 + l) for l in range(nlev)])
+    rng = np.random.default_rng(11)
+    for l in range(nlev):  # level 3 stays clean, levels 5 and 12 (the last of a chunk) are undefined altogether
+        frac = 0.0 if l == 3 else (1.0 if l in (5, nlev - 1) else (0.001, 0.02, 0.3)[l % 3])
+        z[l][rng.random((ny, nx)) < frac] = cases.UNDEF
+    dz, dxm, dym = (torch.from_numpy(a).cuda() for a in (z, xm, ym))
+    flags = np.full(nlev, fc.SOME_DEFINED, np.int32)
+    for name, compute in (("gradient1", 1), ("gradient2", 2)):
+        (o0, _), fo = gpu_ctx.stencil_levels(name, dz, None, dxm, dym, None, fdefined=flags)
+        for l in range(nlev):
+            ok, e, f_e = oracle.call("gradient", nx, ny, z[l], xm, ym, compute, fdefined=fc.SOME_DEFINED)
+            assert ok and f_e == fo[l], (name, l, f_e, fo[l])
+            if l in (0, 3, 5, 7, nlev - 1):
+                assert _bits_equal(o0[l].cpu().numpy(), e), (name, l)
+        # a level without any defined value: SOME_DEFINED for compute 1 (its count never covers the whole field), NONE_DEFINED
+        # for compute 2 -- which pins the kernel's count of such a level exactly
+        empty = fc.SOME_DEFINED if compute == 1 else fc.NONE_DEFINED
+        assert fo[3] == fc.ALL_DEFINED and fo[5] == empty and fo[nlev - 1] == empty, (name, fo)
+
+
 @pytest.mark.parametrize("tune", [None, "K=1", "K=2", "K=2,RB=14", "R=8"])
 def test_masked_single_level_counts(gpu_ctx, oracle, tune, mifc_env):
     """One and two levels with undefined values everywhere through the forms a shallow launch takes (one-shot, one-shot

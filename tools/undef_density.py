@@ -58,6 +58,9 @@ def main():
             del m
         t = timed(lambda: ctx.vortdiv_levels_enqueue(u, dv, dxm, dym, rv, dg, fdefined=flags, n_undefined=cnt))
         print("%-44s %10.4f   (undefined cells counted in level 0: %d)" % ("vortdiv tested, " + name, t, int(cnt[0].item())))
+        for gop in ("gradient1", "gradient3"):  # the level-walking and the row-walking scalar kernels
+            tg = timed(lambda: ctx.stencil_levels(gop, u, None, dxm, dym, None, fdefined=flags, out0=rv))
+            print("%-44s %10.4f" % (gop + " tested, " + name, tg))
         # single-field elementwise operator on the tall field: vectorabs with the tested flag
         tall_u, tall_v = u.view(NLEV * NY, NX), dv.view(NLEV * NY, NX)
         out = rv.view(NLEV * NY, NX)
