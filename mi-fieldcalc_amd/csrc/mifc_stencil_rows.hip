@@ -103,7 +103,10 @@ __device__ __forceinline__ bool scalar_cell(bool all, float undef, float w, floa
       const float g4 = (float)((double)MIFC_K_G * 4.);
       const double d2x = (double)w - 2. * (double)c + (double)e;
       const double d2y = (double)s - 2. * (double)c + (double)n;
-      o0 = (float)((0.25 * dxm * dxm * d2x + 0.25 * dym * dym * d2y) * (double)g4 / (double)fc);
+      // the f64 division through the refined reciprocal: for a float-born divisor it IS the IEEE quotient, bit for bit
+      // (shared_reciprocal() in mifc_device.h; mifc_diag_division checks it), a few instructions shorter than the expansion
+      const double fd = (double)fc;
+      o0 = (float)quotient((0.25 * dxm * dxm * d2x + 0.25 * dym * dym * d2y) * (double)g4, fd, shared_reciprocal(fd));
     }
     return !CHECK || (all | all_def(undef, s, w, c, e, n)); // :2053, :729
   }
@@ -112,13 +115,15 @@ __device__ __forceinline__ bool scalar_cell(bool all, float undef, float w, floa
     const float dfdy = half_prod(ym, n - s);
     o0 = absval(dfdx, dfdy);
   } else if (OP == ST_GWIND_X) { // :661
-    o0 = (float)(-0.5 * (double)ym * (double)(n - s) * (double)MIFC_K_G / (double)fc);
+    const double fd = (double)fc;
+    o0 = (float)quotient(-0.5 * (double)ym * (double)(n - s) * (double)MIFC_K_G, fd, shared_reciprocal(fd));
   } else if (OP == ST_GWIND_Y) { // :694
-    o0 = (float)(0.5 * (double)xm * (double)(e - w) * (double)MIFC_K_G / (double)fc);
-  } else { // ST_IGWIND :1535-1536
-    const double dfc = fc;
-    o0 = (float)(-0.5 * (double)ym * (double)(n - s) / dfc);
-    o1 = (float)(0.5 * (double)xm * (double)(e - w) / dfc);
+    const double fd = (double)fc;
+    o0 = (float)quotient(0.5 * (double)xm * (double)(e - w) * (double)MIFC_K_G, fd, shared_reciprocal(fd));
+  } else { // ST_IGWIND :1535-1536: two quotients by the same divisor share its reciprocal
+    const double fd = (double)fc, finv = shared_reciprocal(fd);
+    o0 = (float)quotient(-0.5 * (double)ym * (double)(n - s), fd, finv);
+    o1 = (float)quotient(0.5 * (double)xm * (double)(e - w), fd, finv);
   }
   return !CHECK || (all | all_def(undef, s, w, e, n)); // :2039, :660, :693, :1534
 }
