@@ -200,7 +200,8 @@ __device__ __forceinline__ bool scalar_from_values(bool all, float undef, float 
       const float g4 = (float)((double)MIFC_K_G * 4.);
       const double d2x = (double)w - 2. * (double)c + (double)e;
       const double d2y = (double)s - 2. * (double)c + (double)n;
-      o.o0 = (float)((0.25 * xm * xm * d2x + 0.25 * ym * ym * d2y) * (double)g4 / (double)fcf);
+      const double fd = (double)fcf; // the division through the refined reciprocal, as in mifc_stencil_rows.hip
+      o.o0 = (float)quotient((0.25 * xm * xm * d2x + 0.25 * ym * ym * d2y) * (double)g4, fd, shared_reciprocal(fd));
     }
     return !CHECK || (all | all_def(undef, s, w, c, e, n)); // :2053, :729
   }
@@ -209,13 +210,15 @@ __device__ __forceinline__ bool scalar_from_values(bool all, float undef, float 
     const float dfdy = half_prod(ymf, n - s);
     o.o0 = absval(dfdx, dfdy);
   } else if (OP == ST_GWIND_X) { // :661
-    o.o0 = (float)(-0.5 * (double)ymf * (double)(n - s) * (double)MIFC_K_G / (double)fcf);
+    const double fd = (double)fcf;
+    o.o0 = (float)quotient(-0.5 * (double)ymf * (double)(n - s) * (double)MIFC_K_G, fd, shared_reciprocal(fd));
   } else if (OP == ST_GWIND_Y) { // :694
-    o.o0 = (float)(0.5 * (double)xmf * (double)(e - w) * (double)MIFC_K_G / (double)fcf);
-  } else { // ST_IGWIND :1535-1536
-    const double fc = fcf;
-    o.o0 = (float)(-0.5 * (double)ymf * (double)(n - s) / fc);
-    o.o1 = (float)(0.5 * (double)xmf * (double)(e - w) / fc);
+    const double fd = (double)fcf;
+    o.o0 = (float)quotient(0.5 * (double)xmf * (double)(e - w) * (double)MIFC_K_G, fd, shared_reciprocal(fd));
+  } else { // ST_IGWIND :1535-1536: two quotients, one reciprocal
+    const double fd = (double)fcf, finv = shared_reciprocal(fd);
+    o.o0 = (float)quotient(-0.5 * (double)ymf * (double)(n - s), fd, finv);
+    o.o1 = (float)quotient(0.5 * (double)xmf * (double)(e - w), fd, finv);
   }
   return !CHECK || (all | all_def(undef, s, w, e, n)); // :2039, :660, :693, :1534
 }
