@@ -736,6 +736,38 @@ def test_masked_level_batch_counts(gpu_ctx, oracle, mifc_env):
                 assert _bits_equal(rv[l].cpu().numpy(), rv_e) and _bits_equal(dg[l].cpu().numpy(), dv_e)
 
 
+@pytest.mark.parametrize("undef", [float("nan"), -32767.0])
+def test_deep_batch_with_an_unusual_undef_value(gpu_ctx, oracle, undef):
+    """The split-role kernel tests a value with ONE compare ("ordered and != undef"), which is is_defined() only for an
+    undef that is not NaN: a caller whose undef IS NaN gets the level-walking kernel with the generic test.  Deep batch,
+    tested flags, NaN and undef values sprinkled, against the reference with the same undef."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 1440, 360, 16
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 77, nlev=nlev)
+    rng = np.random.default_rng(3)
+    for l in range(nlev):
+        if l % 4 == 1:
+            continue  # clean levels
+        u[l][rng.random((ny, nx)) < 0.01] = np.float32(undef)
+        v[l][rng.random((ny, nx)) < 0.01] = np.nan
+        if not np.isnan(undef):
+            v[l][rng.random((ny, nx)) < 0.005] = np.float32(undef)
+    du, dv, dxm, dym = (torch.from_numpy(a).cuda() for a in (u, v, xm, ym))
+    flags = np.full(nlev, fc.SOME_DEFINED, np.int32)
+    (rv, dg), fo = gpu_ctx.vortdiv_levels(du, dv, dxm, dym, fdefined=flags, undef=undef)
+    for l in range(nlev):
+        ok, rv_e, f1 = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=fc.SOME_DEFINED, undef=undef)
+        ok2, dv_e, f2 = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=fc.SOME_DEFINED, undef=undef)
+        assert ok and ok2 and f1 == f2 == fo[l], (l, f1, f2, fo[l])
+        if l in (0, 1, 7, nlev - 1):
+            assert _bits_equal(rv[l].cpu().numpy(), rv_e) and _bits_equal(dg[l].cpu().numpy(), dv_e), l
+
+
 def test_masked_gradient_level_batch_counts(gpu_ctx, oracle):
     """Deep batches of gradient compute 1 / 2 run on the scalar level-walking kernel, which adds a level's undefined counts up
     in LDS and hands one total per workgroup and level to the counter (a masked field used to queue 4 320 same-address
