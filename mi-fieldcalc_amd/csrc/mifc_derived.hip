@@ -143,13 +143,10 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
     if (want_ff) { // vectorabs :1831-1837
       float r[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (wind_all || (is_def(in.u[k], undef) && is_def(in.v[k], undef))) {
-          r[k] = absval(in.u[k], in.v[k]);
-        } else {
-          r[k] = undef;
-          bad_ff += 1;
-        }
+      for (int k = 0; k < 4; ++k) { // straight-line: arithmetic unconditional, the test selects
+        const bool ok = wind_all | all_def(undef, in.u[k], in.v[k]);
+        r[k] = pick(ok, absval(in.u[k], in.v[k]), undef);
+        bad_ff += ok ? 0u : 1u;
       }
       st4(off + o, r);
     }
@@ -157,12 +154,9 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
       float r[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (wind_all || (is_def(in.u[k], undef) && is_def(in.v[k], undef))) {
-          r[k] = wind_direction(in.u[k], in.v[k]);
-        } else {
-          r[k] = undef;
-          bad_dd += 1;
-        }
+        const bool ok = wind_all | all_def(undef, in.u[k], in.v[k]);
+        r[k] = pick(ok, wind_direction(in.u[k], in.v[k]), undef);
+        bad_dd += ok ? 0u : 1u;
       }
       st4(odd + o, r);
     }
@@ -175,9 +169,10 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
         const float pidcp = need_pow ? pidcp_of(PT, p) : 1.f;
         if (want_t) { // hleveltemp :1077-1090
           float r = 0.f;
-          bool ok = thermo_all || (is_def(tt, undef) && is_def(ss, undef));
-          if (ok) {
+          bool ok = thermo_all | all_def(undef, tt, ss);
+          { // unconditional: the point functions are branch-free (clamped table reads), the tests only select
             const float pi = pidcp * MIFC_K_CP;
+            bool okp = true;
             switch (tc) {
             case 1:
               r = tt * pidcp - MIFC_K_T0;
@@ -189,12 +184,13 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
               r = tt / pidcp;
               break;
             case 4:
-              ok = t_thesat(s_ewt, tt, p, pi, r);
+              okp = t_thesat(s_ewt, tt, p, pi, r);
               break;
             default:
-              ok = th_thesat(s_ewt, tt, p, pi, r);
+              okp = th_thesat(s_ewt, tt, p, pi, r);
               break;
             }
+            ok = ok & okp;
           }
           rt[k] = ok ? r : undef;
           bad_t += ok ? 0u : 1u;
@@ -203,14 +199,14 @@ __global__ __launch_bounds__(256) void derived_levels_kernel(const DerivedParams
           float r = 0.f;
           // the point function runs unconditionally (branch-free: its table reads are clamped), the tests only select
           const bool okp = hum_point(hc, s_ewt, tt, hh, h_need_p ? p : 0.f, pidcp, P.hum_tdconv, r);
-          const bool ok = (thermo_all || (is_def(tt, undef) && is_def(hh, undef) && (!h_need_p || ss != undef))) && okp;
+          const bool ok = (thermo_all | (all_def(undef, tt, hh) & (!h_need_p | (ss != undef)))) & okp;
           rh[k] = ok ? r : undef;
           bad_h += ok ? 0u : 1u;
         }
         if (want_d) {
           float r = 0.f;
           const bool okp = hum_point(dc, s_ewt, tt, hh, d_need_p ? p : 0.f, pidcp, P.td_tdconv, r);
-          const bool ok = (thermo_all || (is_def(tt, undef) && is_def(hh, undef) && (!d_need_p || ss != undef))) && okp;
+          const bool ok = (thermo_all | (all_def(undef, tt, hh) & (!d_need_p | (ss != undef)))) & okp;
           rd[k] = ok ? r : undef;
           bad_d += ok ? 0u : 1u;
         }
