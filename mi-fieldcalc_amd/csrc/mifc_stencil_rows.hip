@@ -726,8 +726,16 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   switch (op) {
   case ST_GRAD_X:
     launch_op<ST_GRAD_X>(rp, check, form, grid, lds, stream);
-    if (check && rp.n_undefined)
-      hipLaunchKernelGGL(gradx_outer_rows_count_kernel, dim3((unsigned)((2 * (nx - 1) + 255) / 256), (unsigned)prm.nlev), dim3(256), 0, stream, rp);
+    if (check && rp.n_undefined) {
+      for (int l0 = 0; l0 < prm.nlev; l0 += 65535) { // grid.y limit
+        SRowsParams cp = rp;
+        const int nl = prm.nlev - l0 > 65535 ? 65535 : prm.nlev - l0;
+        cp.f = rp.f + (size_t)l0 * rp.in_stride;
+        cp.all_defined = rp.all_defined ? rp.all_defined + l0 : nullptr;
+        cp.n_undefined = rp.n_undefined + l0;
+        hipLaunchKernelGGL(gradx_outer_rows_count_kernel, dim3((unsigned)((2 * (nx - 1) + 255) / 256), (unsigned)nl), dim3(256), 0, stream, cp);
+      }
+    }
     break;
   case ST_GRAD_Y:
     launch_op<ST_GRAD_Y>(rp, check, form, grid, lds, stream);
