@@ -386,6 +386,12 @@ hipError_t launch_shapiro2_fused_levels(int nx, int ny, int all_defined, float u
     const long waves_wanted = env().fused2_band > 0 ? 0 : 256L * 4 * 8 * 3 - 256;
     const long want_bands = (waves_wanted + (long)ntiles * n_launch_levels - 1) / ((long)ntiles * n_launch_levels);
     int band = env().fused2_band > 0 ? env().fused2_band : (int)((ny + (want_bands > 0 ? want_bands : 1) - 1) / (want_bands > 0 ? want_bands : 1));
+    if (band < 4 && env().fused2_band <= 0) {
+      // a launch too small for three rounds even with 4-row bands: bands for ONE round of the chip instead (a band of b rows
+      // costs b + 4 iterations; 4000 x 4000, one level: 17 000 waves of 8 iterations -> 7 565 of 13)
+      const long slots = 256L * 4 * 8 / ((long)ntiles * n_launch_levels);
+      band = slots > 0 ? (int)((ny + slots - 1) / slots) : 128;
+    }
     if (band < 4)
       band = 4;
     if (band > 128)

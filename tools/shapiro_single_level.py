@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""measurement only (tools/): single-field shapiro2_filter calls on device-resident fields, us per call (20 back to back)."""
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd())
 import torch
@@ -5,7 +7,7 @@ import mi_fieldcalc_amd as fc
 import mi_fieldcalc_amd.synth as synth
 dev = torch.device("cuda", 0)
 ctx = fc.Context(0); ctx.use_torch_stream()
-for nx, ny in ((1440, 720), (4000, 4000), (256, 256)):
+for nx, ny in ((1440, 720), (4000, 4000), (256, 256), (2880, 1440)):
     z = torch.from_numpy(synth.scalar_field(nx, ny, 5)).to(dev)
     out = torch.empty_like(z)
     for flag, name in ((fc.ALL_DEFINED, "ALL"), (fc.SOME_DEFINED, "SOME")):
