@@ -322,6 +322,21 @@ enum {
 int mifc_stencil_levels(mifc_ctx* ctx, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* xmapr, const float* ymapr,
                         const float* fcoriolis, float* out0, float* out1, int* fdefined, float undef, int memkind);
 
+/* Asynchronous form of mifc_stencil_levels, device pointers only (the generic form of
+ * mifc_vortdiv_levels_enqueue): enqueues on the context's stream and returns; nothing is read back.
+ * fdefined_in : host int[nlev] or NULL (= every level MIFC_SOME_DEFINED), read before returning.
+ * n_undefined_dev : device array of nlev 64-bit counters, zeroed by the call and filled by the kernel
+ * (NULL allowed when every level is MIFC_ALL_DEFINED).  Once the stream has drained the flag of level l
+ * is mifc_classify(n_undefined[l], mifc_stencil_count_domain(op, nx, ny)) -- except MIFC_OP_GWIND_X,
+ * which is MIFC_NONE_DEFINED whatever the count (FieldCalculations.cc:664).  This is the entry a caller
+ * captures into a HIP graph or issues back to back without a host round trip per operator. */
+int mifc_stencil_levels_enqueue(mifc_ctx* ctx, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* xmapr,
+                                const float* ymapr, const float* fcoriolis, float* out0, float* out1, const int* fdefined_in, float undef,
+                                unsigned long long* n_undefined_dev);
+/* what a level's undefined count of `op` is classified against: nx*ny - 2*nx (FieldCalculations.cc:1868 and
+ * friends, also gradient compute 1, :2068), nx*ny for MIFC_OP_IGWIND (:1543) */
+unsigned long long mifc_stencil_count_domain(int op, int nx, int ny);
+
 /* The same plus the rest of the stencil family over a batch of levels, the map
  * and Coriolis fields shared by all levels:
  *   MIFC_OP_ADVECTION .cc:1942  f0 = f, f1 = u, f2 = v, scalar = hours

@@ -588,6 +588,8 @@ class Context:
         if _memkind([au, av, ax, ay, ar, ad], self.device) != MEM_DEVICE:
             raise ValueError("the *_enqueue calls take device tensors only")
         outs = [a for a in (ar, ad) if a.addr is not None]
+        if not outs:
+            raise ValueError("at least one of rvort, diverg is required")
         if av.lstride != au.lstride or (len(outs) == 2 and outs[0].lstride != outs[1].lstride):
             raise ValueError("u and v (and rvort and diverg) must share one level stride")
         flags = None if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
@@ -601,6 +603,31 @@ class Context:
             ],
         )
         return bool(rc)
+
+    def stencil_levels_enqueue(self, op, f0, f1, xmapr, ymapr, fcoriolis, out0, out1=None, fdefined=None, undef=UNDEF, n_undefined=None):
+        """Asynchronous form of stencil_levels on device tensors (mifc_stencil_levels_enqueue): nothing is read back;
+        n_undefined: int64 CUDA tensor[nlev] (None allowed when every level is ALL_DEFINED).  The flag of level l is
+        classify(n_undefined[l], stencil_count_domain(op, nx, ny)) once the stream has drained."""
+        code = self.OPS[op]
+        a0, a1 = _Arg(f0), _Arg(f1, allow_none=True)
+        ax, ay, af = _Arg(xmapr), _Arg(ymapr), _Arg(fcoriolis, allow_none=True)
+        o0, o1 = _Arg(out0, allow_none=True, output=True), _Arg(out1, allow_none=True, output=True)
+        if len(a0.shape) != 3:
+            raise ValueError("level fields must be (nlev, ny, nx)")
+        nlev, ny, nx = a0.shape
+        if not _same_shape([a1, o0, o1], a0.shape) or not _same_shape([ax, ay, af], (ny, nx)):
+            raise ValueError("level fields must be (nlev, ny, nx) and the map / Coriolis fields (ny, nx)")
+        if _memkind([a0, a1, ax, ay, af, o0, o1], self.device) != MEM_DEVICE:
+            raise ValueError("the *_enqueue calls take device tensors only")
+        flags = None if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
+        self._bind_stream(MEM_DEVICE)
+        rc = self._call("mifc_stencil_levels_enqueue", [code, nx, ny, nlev, a0.addr, a1.addr, ax.addr, ay.addr, af.addr, o0.addr, o1.addr,
+                                                        None if flags is None else flags.ctypes.data, float(undef),
+                                                        None if n_undefined is None else n_undefined.data_ptr()])
+        return bool(rc)
+
+    def stencil_count_domain(self, op, nx, ny):
+        return int(self._lib.mifc_stencil_count_domain(self.OPS[op], nx, ny))
 
     def batch_level_stride(self, nx, ny):
         """Recommended distance (floats) between the levels of a device-resident batch (mifc_batch_level_stride)."""

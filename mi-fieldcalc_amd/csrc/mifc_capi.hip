@@ -365,9 +365,14 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
   // undefined values in it needs no flag upload
   P.all_defined = any_all ? c->d_flags : nullptr;
   if (!every_all) {
-    if (any_all)
-      MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)sc.nlev, hipMemcpyHostToDevice, c->stream));
-    MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64) * (size_t)sc.nlev, c->stream));
+    // flags (bit-packed in the kernel arguments) and zeroed counters by one small kernel; very deep batches copy and fill
+    if (sc.nlev <= mifc::kPrepMaxLevels) {
+      MIFC_HIP(c, mifc::launch_prep_levels(any_all ? pinned_flags(c) : nullptr, sc.nlev, c->d_flags, c->d_counts, sc.nlev, c->stream));
+    } else {
+      if (any_all)
+        MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)sc.nlev, hipMemcpyHostToDevice, c->stream));
+      MIFC_HIP(c, hipMemsetAsync(c->d_counts, 0, sizeof(u64) * (size_t)sc.nlev, c->stream));
+    }
   }
   if (piped) {
     MIFC_HIP(c, hipStreamSynchronize(c->stream)); // maps, flags and zeroed counters are in place
@@ -1518,11 +1523,63 @@ int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const flo
   return mifc_vortdiv_levels_strided_enqueue(c, nx, ny, nlev, u, v, xmapr, ymapr, rvort, diverg, n, n, fdefined_in, undef, n_undefined_dev);
 }
 
+unsigned long long mifc_stencil_count_domain(int op, int nx, int ny)
+{
+  return stencil_denominator(op, nx, ny);
+}
+
 size_t mifc_batch_level_stride(int nx, int ny)
 {
   if (nx <= 0 || ny <= 0)
     return 0;
   return mifc::padded_level_stride((size_t)nx * (size_t)ny);
+}
+
+// what the asynchronous level-batch entries share: flags up, counters zeroed, one launch, nothing read back
+static int stencil_enqueue(mifc_ctx* c, const char* who, mifc::StencilParams& P, const int* fdefined_in, unsigned long long* n_undefined_dev)
+{
+  if (!ensure_levels(c, (size_t)P.nlev))
+    return 0;
+  bool every_all = (fdefined_in != nullptr), any_all = false;
+  for (int l = 0; l < P.nlev; ++l) {
+    const bool a = fdefined_in && fdefined_in[l] == MIFC_ALL_DEFINED;
+    every_all = every_all && a;
+    any_all = any_all || a;
+  }
+  P.every_level_all_defined = every_all ? 1 : 0;
+  P.all_defined = any_all ? c->d_flags : nullptr; // the kernels read a null flag array as "no level is ALL_DEFINED"
+  P.n_undefined = n_undefined_dev;
+  if (!every_all && !n_undefined_dev) {
+    c->err = std::string(who) + ": n_undefined_dev is required unless every level is ALL_DEFINED";
+    return 0;
+  }
+  const bool upload = !every_all && any_all;
+  if (P.nlev <= mifc::kPrepMaxLevels) {
+    // flags (bit-packed in the kernel arguments) and zeroed counters by ONE small kernel in front of the operator's
+    std::vector<unsigned char> hf;
+    if (upload) {
+      hf.resize((size_t)P.nlev);
+      for (int l = 0; l < P.nlev; ++l)
+        hf[l] = fdefined_in[l] == MIFC_ALL_DEFINED ? 1 : 0;
+    }
+    MIFC_HIP(c, mifc::launch_prep_levels(upload ? hf.data() : nullptr, P.nlev, c->d_flags, n_undefined_dev, P.nlev, c->stream));
+  } else {
+    if (upload) {
+      if (!pinned_acquire(c))
+        return 0;
+      for (int l = 0; l < P.nlev; ++l)
+        pinned_flags(c)[l] = fdefined_in[l] == MIFC_ALL_DEFINED ? 1 : 0;
+      MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)P.nlev, hipMemcpyHostToDevice, c->stream));
+      if (!pinned_release(c))
+        return 0;
+    }
+    if (n_undefined_dev)
+      MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64) * (size_t)P.nlev, c->stream));
+  }
+  MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
+  if (upload && !scratch_release(c)) // the kernel reads c->d_flags
+    return 0;
+  return 1;
 }
 
 int mifc_vortdiv_levels_strided_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
@@ -1538,8 +1595,6 @@ int mifc_vortdiv_levels_strided_enqueue(mifc_ctx* c, int nx, int ny, int nlev, c
     c->err = "mifc_vortdiv_levels_strided_enqueue: a level stride is smaller than one field";
     return 0;
   }
-  if (!ensure_levels(c, (size_t)nlev))
-    return 0;
   mifc::StencilParams P;
   std::memset(&P, 0, sizeof P);
   P.op = mifc::ST_VORTDIV;
@@ -1564,32 +1619,50 @@ int mifc_vortdiv_levels_strided_enqueue(mifc_ctx* c, int nx, int ny, int nlev, c
   P.in_level_stride = (long)in_level_stride;
   P.out_level_stride = (long)out_level_stride;
   P.undef = undef;
-  if (!pinned_acquire(c))
+  return stencil_enqueue(c, "mifc_vortdiv_levels_enqueue", P, fdefined_in, n_undefined_dev);
+}
+
+int mifc_stencil_levels_enqueue(mifc_ctx* c, int op, int nx, int ny, int nlev, const float* f0, const float* f1, const float* xmapr, const float* ymapr,
+                                const float* fcoriolis, float* out0, float* out1, const int* fdefined_in, float undef,
+                                unsigned long long* n_undefined_dev)
+{
+  if (!c)
     return 0;
-  bool every_all = (fdefined_in != nullptr);
-  for (int l = 0; l < nlev; ++l) {
-    const bool a = fdefined_in && fdefined_in[l] == MIFC_ALL_DEFINED;
-    pinned_flags(c)[l] = a ? 1 : 0;
-    every_all = every_all && a;
-  }
-  P.every_level_all_defined = every_all ? 1 : 0;
-  P.all_defined = c->d_flags;
-  P.n_undefined = n_undefined_dev;
-  if (!every_all) {
-    if (!n_undefined_dev) {
-      c->err = "mifc_vortdiv_levels_enqueue: n_undefined_dev is required unless every level is ALL_DEFINED";
-      return 0;
-    }
-    MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)nlev, hipMemcpyHostToDevice, c->stream));
-    if (!pinned_release(c))
-      return 0;
-  }
-  if (n_undefined_dev)
-    MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64) * (size_t)nlev, c->stream));
-  MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
-  if (!every_all && !scratch_release(c)) // the kernel reads c->d_flags
+  enter(c);
+  if (!((op >= mifc::ST_RELVORT && op <= mifc::ST_IGWIND) || op == mifc::ST_JACOBIAN) || !f0 || nx < 3 || ny < 3 || nlev < 1 || !xmapr || !ymapr)
     return 0;
-  return 1;
+  const bool wind = (op <= mifc::ST_VORTDIV) || op == mifc::ST_JACOBIAN; // two input fields per level
+  const bool needs_fc = op == mifc::ST_ABSVORT || (op >= mifc::ST_GWIND_X && op <= mifc::ST_IGWIND);
+  if ((wind && !f1) || (needs_fc && !fcoriolis) || (op == mifc::ST_IGWIND && !out1))
+    return 0;
+  if (op == mifc::ST_VORTDIV ? (!out0 && !out1) : !out0)
+    return 0;
+  mifc::StencilParams P;
+  std::memset(&P, 0, sizeof P);
+  P.op = op;
+  P.out0 = out0;
+  P.out1 = (op == mifc::ST_VORTDIV || op == mifc::ST_IGWIND) ? out1 : nullptr;
+  if (op == mifc::ST_VORTDIV && !out0) {
+    P.op = mifc::ST_DIVERGENCE;
+    P.out0 = out1;
+    P.out1 = nullptr;
+  } else if (op == mifc::ST_VORTDIV && !out1) {
+    P.op = mifc::ST_RELVORT;
+  }
+  P.nx = nx;
+  P.ny_global = ny;
+  P.j0 = 0;
+  P.ny_local = ny;
+  P.nlev = nlev;
+  P.f0 = f0;
+  P.f1 = wind ? f1 : nullptr;
+  P.xmapr = xmapr;
+  P.ymapr = ymapr;
+  P.fcoriolis = needs_fc ? fcoriolis : nullptr;
+  P.in_level_stride = (long)nx * ny;
+  P.out_level_stride = (long)nx * ny;
+  P.undef = undef;
+  return stencil_enqueue(c, "mifc_stencil_levels_enqueue", P, fdefined_in, n_undefined_dev);
 }
 
 } // extern "C"

@@ -543,6 +543,28 @@ __device__ __forceinline__ float wind_direction(float u, float v)
   return dd;
 }
 
+// ---- the input flag of a level inside a level-walking kernel
+// flags[lev] != 0 <=> the level's input flag is ALL_DEFINED (no tests).  gfx9 has no scalar byte load, so the plain
+// expression flags[lev] compiles into global_load_ubyte + s_waitcnt vmcnt(0): one more entry in the wave's in-order
+// vector-memory queue, BEHIND every store (and prefetch) the wave still has in flight -- the wait for one byte is a wait
+// for all of them, once per level, which is exactly the load/store coupling the split-role kernels exist to avoid
+// (round 3: their tested variants ran 4-50 % behind the untested ones because of it).  This reads the aligned dword
+// around the byte through the scalar cache instead (lgkmcnt, which the level's barrier waits for anyway) and returns
+// after the workgroup barrier of the level: `s_waitcnt lgkmcnt(0); s_barrier` with the flag for free.
+// The flag arrays are the context's (capacity a multiple of 4, 256-byte aligned base), so the dword never leaves them.
+__device__ __forceinline__ bool level_flag_then_barrier(const unsigned char* flags /* wave-uniform, may be null */, int lev /* wave-uniform */)
+{
+  if (flags == nullptr) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    return false;
+  }
+  const unsigned long long a = (unsigned long long)(flags + lev);
+  const unsigned long long base = a & ~3ull;
+  unsigned int w;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : "=&s"(w) : "s"(base) : "memory");
+  return ((w >> ((unsigned int)(a & 3ull) * 8u)) & 0xffu) != 0u;
+}
+
 // ---- undefined-cell counting
 // Atomics to ONE address are served one after the other (~12 ns each on MI355X: profiles/r02/experiments/undef_density.txt);
 // a masked field, where every wave has something to count, turned the 0.3 ms of a one-shot elementwise kernel into

@@ -23,10 +23,11 @@ struct Env
   int derived_blocks = 0;         // MIFC_DERIVED_BLOCKS (> 0 overrides the persistent grid of the fused derived kernel)
   int derived_pipe = 1;           // MIFC_DERIVED_PIPE=0: the fused derived kernel without the two-trip software pipeline (A/B)
   bool levelwalk = true;          // MIFC_VORTDIV_LEVELWALK=0: deep wind batches on the row-walking kernel (A/B)
-  bool split_roles = true;        // MIFC_VORTDIV_SPLIT=0: the fused pair of a deep batch on the level-walking kernel whose waves load AND store (A/B)
+  bool split_roles = true;        // MIFC_VORTDIV_SPLIT=0: deep batches of the stencil operators on the level-walking kernels whose waves load AND store (A/B)
   int levelwalk_min_units = 0;    // MIFC_LEVELWALK_MIN_UNITS (> 0 overrides the launch size from which the level-walking forms are chosen; tests)
   bool has_vortdiv_tune = false;  // MIFC_VORTDIV_TUNE="R=8,D=1,..."
   char vortdiv_tune[256] = {0};
+  char scalar_split_tune[64] = {0}; // MIFC_SCALAR_SPLIT_TUNE="TR=12,NL=2,PF=2,LG=6": shape of the split-role form of the one-input stencil operators (A/B, tests)
 };
 
 // the current snapshot (defaults until the first reload)

@@ -57,6 +57,8 @@ void env_reload()
     e.has_vortdiv_tune = true;
     std::strncpy(e.vortdiv_tune, s, sizeof e.vortdiv_tune - 1);
   }
+  if (const char* s = std::getenv("MIFC_SCALAR_SPLIT_TUNE"))
+    std::strncpy(e.scalar_split_tune, s, sizeof e.scalar_split_tune - 1);
   std::lock_guard<std::mutex> lock(g_env_mutex);
   g_env = e;
 }

@@ -253,6 +253,13 @@ struct StencilParams
 
 hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream);
 
+// What a level-batch launch needs in place beforehand, as ONE small kernel instead of a host-to-device copy plus a fill
+// (two stream operations on two engines: ~10 us of a 0.2 ms launch): the per-level input flags travel bit-packed in the
+// kernel arguments and are expanded into d_flags (u8[nlev], null: none needed), d_counts[0 .. n_counts) is zeroed
+// (null: nothing to zero).  Returns hipErrorInvalidValue beyond kPrepMaxLevels levels (the caller then copies and fills).
+constexpr int kPrepMaxLevels = 2048;
+hipError_t launch_prep_levels(const unsigned char* host_flags, int nlev, unsigned char* d_flags, u64* d_counts, int n_counts, hipStream_t stream);
+
 // second-order Shapiro filter, FieldCalculations.cc:2076 (mifc_shapiro.hip)
 struct ShapiroParams
 {

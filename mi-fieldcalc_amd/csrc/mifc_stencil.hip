@@ -577,6 +577,48 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
 hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool* handled);  // mifc_stencil_rows.hip
 hipError_t launch_advection_oneshot(const StencilParams& prm, hipStream_t stream, bool* handled); // mifc_advection.hip
 
+namespace {
+struct PrepLevels
+{
+  unsigned char* flags;
+  u64* counts;
+  int nlev, n_counts;
+  unsigned int bits[kPrepMaxLevels / 32];
+};
+__global__ __launch_bounds__(256) void prep_levels_kernel(const PrepLevels P)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (P.flags && i < P.nlev)
+    P.flags[i] = (unsigned char)((P.bits[i >> 5] >> (i & 31)) & 1u);
+  if (P.counts && i < P.n_counts)
+    P.counts[i] = 0;
+}
+} // namespace
+
+hipError_t launch_prep_levels(const unsigned char* host_flags, int nlev, unsigned char* d_flags, u64* d_counts, int n_counts, hipStream_t stream)
+{
+  if (!host_flags)
+    d_flags = nullptr;
+  if ((d_flags && nlev > kPrepMaxLevels) || nlev < 0 || n_counts < 0)
+    return hipErrorInvalidValue;
+  const int n = (d_flags ? nlev : 0) > (d_counts ? n_counts : 0) ? nlev : (d_counts ? n_counts : 0);
+  if (n == 0)
+    return hipSuccess;
+  PrepLevels P;
+  P.flags = d_flags;
+  P.counts = d_counts;
+  P.nlev = nlev;
+  P.n_counts = n_counts;
+  for (unsigned int& w : P.bits)
+    w = 0;
+  if (d_flags)
+    for (int l = 0; l < nlev; ++l)
+      if (host_flags[l])
+        P.bits[l >> 5] |= 1u << (l & 31);
+  hipLaunchKernelGGL(prep_levels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P);
+  return hipGetLastError();
+}
+
 hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
 {
   if (prm.nlev <= 0)

@@ -16,8 +16,7 @@
 //     stores.
 // Algorithmic traffic: 4 B read + 4 B written per cell (8 B written for
 // ilevelgwind), map factors once per batch.
-#include "mifc_device.h"
-#include "mifc_kernels.h"
+#include "mifc_scalar_cell.h"
 
 #include <cstdlib>
 
@@ -25,108 +24,12 @@ namespace mifc {
 
 namespace {
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-struct SRowsParams
-{
-  int nx, ny;
-  int R, nbands, nwc, nlev, wpb;
-  int uL, uB, uW, n_logical, per_xcd;
-  const float* f;
-  const float *xm, *ym, *fc; // any may be null when the operator does not use it
-  float *o0, *o1;
-  long in_stride, out_stride;
-  const unsigned char* all_defined;
-  float undef;
-  u64* n_undefined;
-};
-
-__device__ __forceinline__ float dpp_lower(float keep_if_none, float x)
-{
-  return __builtin_bit_cast(float,
-                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float dpp_upper(float keep_if_none, float x)
-{
-  return __builtin_bit_cast(float,
-                            __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep_if_none), __builtin_bit_cast(int, x), 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_value(float x, int src_lane) // by value: see mifc_vortdiv.hip
-{
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src_lane));
-}
-__device__ __forceinline__ v4f ld4(const float* p)
-{
-  return *reinterpret_cast<const v4f*>(p);
-}
-__device__ __forceinline__ void st4_stream(float* p, const float (&z)[4])
-{
-  v4f t;
-  t.x = z[0];
-  t.y = z[1];
-  t.z = z[2];
-  t.w = z[3];
-  __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(p));
-}
-
 template <int V>
 struct SRow
 {
   v4f f[V];
   float e; // lane 63: value east of the wave-column; other lanes: value west of it
 };
-
-// One cell of operator OP.  w, c, e: row j; s, n: rows j-1, j+1.  Returns false
-// when the cell is undefined.  Formulas are those of stencil_raw() in
-// mifc_stencil.hip, i.e. of the reference lines cited there.
-template <int OP, bool CHECK>
-__device__ __forceinline__ bool scalar_cell(bool all, float undef, float w, float c, float e, float s, float n, float xm, float ym, float fc, float& o0,
-                                            float& o1)
-{
-  // straight-line code: the tests are combined without short-circuits, the formula runs unconditionally (on undefined
-  // inputs it produces some number, infinity or NaN that the caller's select discards) -- see all_def()
-  if (OP == ST_GRAD_X) { // :2015-2016
-    o0 = half_prod(xm, e - w);
-    return !CHECK || (all | all_def(undef, w, e));
-  }
-  if (OP == ST_GRAD_Y) { // :2027-2028
-    o0 = half_prod(ym, n - s);
-    return !CHECK || (all | all_def(undef, s, n));
-  }
-  if (OP == ST_GRAD_LAP || OP == ST_GVORT) {
-    const double dxm = xm, dym = ym;
-    if (OP == ST_GRAD_LAP) { // :2054-2056
-      const float d2x = (float)((double)w - 2.0 * (double)c + (double)e);
-      const float d2y = (float)((double)s - 2.0 * (double)c + (double)n);
-      o0 = (float)(4.0 * (0.25 * dxm * dxm * (double)d2x + 0.25 * dym * dym * (double)d2y));
-    } else { // :730-731
-      const float g4 = (float)((double)MIFC_K_G * 4.);
-      const double d2x = (double)w - 2. * (double)c + (double)e;
-      const double d2y = (double)s - 2. * (double)c + (double)n;
-      // the f64 division through the refined reciprocal: for a float-born divisor it IS the IEEE quotient, bit for bit
-      // (shared_reciprocal() in mifc_device.h; mifc_diag_division checks it), a few instructions shorter than the expansion
-      const double fd = (double)fc;
-      o0 = (float)quotient((0.25 * dxm * dxm * d2x + 0.25 * dym * dym * d2y) * (double)g4, fd, shared_reciprocal(fd));
-    }
-    return !CHECK || (all | all_def(undef, s, w, c, e, n)); // :2053, :729
-  }
-  if (OP == ST_GRAD_ABS) { // :2040-2042
-    const float dfdx = half_prod(xm, e - w);
-    const float dfdy = half_prod(ym, n - s);
-    o0 = absval(dfdx, dfdy);
-  } else if (OP == ST_GWIND_X) { // :661
-    const double fd = (double)fc;
-    o0 = (float)quotient(-0.5 * (double)ym * (double)(n - s) * (double)MIFC_K_G, fd, shared_reciprocal(fd));
-  } else if (OP == ST_GWIND_Y) { // :694
-    const double fd = (double)fc;
-    o0 = (float)quotient(0.5 * (double)xm * (double)(e - w) * (double)MIFC_K_G, fd, shared_reciprocal(fd));
-  } else { // ST_IGWIND :1535-1536: two quotients by the same divisor share its reciprocal
-    const double fd = (double)fc, finv = shared_reciprocal(fd);
-    o0 = (float)quotient(-0.5 * (double)ym * (double)(n - s), fd, finv);
-    o1 = (float)quotient(0.5 * (double)xm * (double)(e - w), fd, finv);
-  }
-  return !CHECK || (all | all_def(undef, s, w, e, n)); // :2039, :660, :693, :1534
-}
 
 template <int OP, bool CHECK, int V>
 __global__ __launch_bounds__(1024) void scalar_rows_kernel(const SRowsParams P)
@@ -486,7 +389,12 @@ __global__ __launch_bounds__(64 * LW_WAVES, 6) void scalar_levelwalk_kernel(cons
       sf[buf][wave][lane] = C.f;
       // only the LDS counter is waited for: the prefetch above and earlier stores stay in flight.  Two buffers: a
       // wave can overwrite buffer b again only after the barrier of the level in between.
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // (the level's input flag through the scalar cache, with the same wait: level_flag_then_barrier, mifc_device.h)
+      bool all = true;
+      if (CHECK)
+        all = level_flag_then_barrier(P.all_defined, lev);
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (CHECK && P.n_undefined && threadIdx.x == 0 && lev > lev0) { // the previous level's adds are complete
         const int q = (lev - 1 - lev0) & 1;
         const unsigned int n = sbad[q];
@@ -496,7 +404,6 @@ __global__ __launch_bounds__(64 * LW_WAVES, 6) void scalar_levelwalk_kernel(cons
         }
       }
       if (computes) {
-        const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
         const v4f fn = sf[buf][wave + 1][lane], fs = sf[buf][wave - 1][lane];
         const float east = lane_value(C.e, 63);
         const float fW = dpp_lower(C.e, C.f.w);
@@ -723,19 +630,30 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   }
 
   *handled = true;
+  auto count_outer_rows = [&]() { // gradient compute 1 with tests: the share of rows 0 and ny-1 (see gradx_outer_rows_count_kernel)
+    if (!(check && rp.n_undefined))
+      return;
+    for (int l0 = 0; l0 < prm.nlev; l0 += 65535) { // grid.y limit
+      SRowsParams cp = rp;
+      const int nl = prm.nlev - l0 > 65535 ? 65535 : prm.nlev - l0;
+      cp.f = rp.f + (size_t)l0 * rp.in_stride;
+      cp.all_defined = rp.all_defined ? rp.all_defined + l0 : nullptr;
+      cp.n_undefined = rp.n_undefined + l0;
+      hipLaunchKernelGGL(gradx_outer_rows_count_kernel, dim3((unsigned)((2 * (nx - 1) + 255) / 256), (unsigned)nl), dim3(256), 0, stream, cp);
+    }
+  };
+  // Deep batches, round 3: the level-walking tiles with split roles (mifc_stencil_split.hip) -- loader waves fill LDS two
+  // levels ahead, compute waves only read LDS and store, two workgroups per CU -- for every operator of the family.
+  if (form != 0 && forced_r < 0 && scalar_split_applies(op, nx, ny, prm.nlev, check, prm.undef)) {
+    const hipError_t e = launch_scalar_split(op, rp, check, stream);
+    if (e == hipSuccess && op == ST_GRAD_X)
+      count_outer_rows();
+    return e != hipSuccess ? e : hipGetLastError();
+  }
   switch (op) {
   case ST_GRAD_X:
     launch_op<ST_GRAD_X>(rp, check, form, grid, lds, stream);
-    if (check && rp.n_undefined) {
-      for (int l0 = 0; l0 < prm.nlev; l0 += 65535) { // grid.y limit
-        SRowsParams cp = rp;
-        const int nl = prm.nlev - l0 > 65535 ? 65535 : prm.nlev - l0;
-        cp.f = rp.f + (size_t)l0 * rp.in_stride;
-        cp.all_defined = rp.all_defined ? rp.all_defined + l0 : nullptr;
-        cp.n_undefined = rp.n_undefined + l0;
-        hipLaunchKernelGGL(gradx_outer_rows_count_kernel, dim3((unsigned)((2 * (nx - 1) + 255) / 256), (unsigned)nl), dim3(256), 0, stream, cp);
-      }
-    }
+    count_outer_rows();
     break;
   case ST_GRAD_Y:
     launch_op<ST_GRAD_Y>(rp, check, form, grid, lds, stream);

@@ -1,0 +1,402 @@
+// mifc_stencil_split.hip -- split-role level-walking form of the single-input stencil operators: gradient compute 1..4
+// (FieldCalculations.cc:1985-2074), plevelgwind_xcomp (:638), plevelgwind_ycomp (:674), plevelgvort (:708),
+// ilevelgwind (:1511) over a deep batch of levels.
+//
+// The design of vortdiv_split_kernel (mifc_vortdiv.hip) with one input field:
+//   * a workgroup owns a tile of TR rows x 256 columns and walks through a chunk of levels; the tile's map factors and
+//     Coriolis parameter live in registers for the whole walk (map factors once per chunk of levels);
+//   * NL loader waves bring the TR + 2 rows of a level (and the two edge scalars of every row) straight from global
+//     memory into LDS (global_load_lds: no registers, no ds_write), PF levels ahead, into a ring of PF + 1 level buffers;
+//   * TR compute waves (one row each) take their row, the rows above and below and the edge scalars from LDS, the
+//     x-neighbours from the adjacent lanes (DPP), and store 1 KiB (2 for ilevelgwind) nontemporally: the only entries in
+//     their vmcnt queue are stores, which nothing in the loop waits for.  On gfx9 a wave's loads and stores share one
+//     in-order counter; a wave that does both sees the data of level l + 1 only after its stores of level l - 1 have been
+//     acknowledged (the coupling the copy yardsticks price at 10-15 %);
+//   * ONE barrier per level; a workgroup holds (PF + 1) x (TR + 2) KiB of LDS and at most 64 VGPRs per lane, so TWO
+//     workgroups share a CU and their arithmetic phases (a correctly rounded square root, f64 quotients) overlap each
+//     other's memory time -- what the first level-walking form (all waves of a CU in step) lacked for the heavy operators;
+//   * undefined counts: compute waves add into one of two LDS slots, the last loader hands the total of level l to the
+//     level's counter after the barrier of level l + 1 -- one global atomic per workgroup and level.
+// Flat-loop semantics as in the other forms: the edge scalars are the flat neighbours i - 1 / i + 1 (wrapped into the
+// adjacent row at columns 0 / nx - 1, clamped to the field), fillEdges is folded into the stores.
+#include "mifc_scalar_cell.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+namespace mifc {
+
+namespace {
+
+template <int OP, bool CHECK, int TR, int NL, int PF>
+__global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 3) / 4 : 1) void scalar_split_kernel(const SRowsParams P)
+{
+  constexpr bool USE_XM = (OP != ST_GRAD_Y && OP != ST_GWIND_X);
+  constexpr bool USE_YM = (OP != ST_GRAD_X && OP != ST_GWIND_Y);
+  constexpr bool USE_FC = (OP == ST_GWIND_X || OP == ST_GWIND_Y || OP == ST_GVORT || OP == ST_IGWIND);
+  constexpr bool TWO_OUT = (OP == ST_IGWIND);
+  constexpr bool NEED_X = USE_XM; // the operator reads the x-neighbours, hence the edge scalars
+  constexpr int NB = PF + 1;               // level buffers
+  constexpr int NS = TR + 2;               // row slots per level: slot s holds tile row s - 1
+  constexpr int KMAX = (NS + NL - 1) / NL; // row slots per loader wave
+  static_assert(2 * NS <= 64, "the edge scalars of a level are one dword per lane");
+  __shared__ v4f srow[NB][NS][64];
+  __shared__ float sedge[NB][64]; // [buffer][2 * slot + (west | east)]
+  __shared__ unsigned int sbad[2];
+  if (CHECK && threadIdx.x < 2)
+    sbad[threadIdx.x] = 0; // ordered before the first use by the barrier of the first level
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int bid = blockIdx.x;
+  const int seq = (bid & 7) * P.per_xcd + (bid >> 3);
+  if (seq >= P.n_logical)
+    return;
+  // unit = (level chunk, row block, column segment), column segment fastest
+  const int ntiles = P.uB * P.uW;
+  const int lchunk = seq / ntiles;
+  const int tile = seq - lchunk * ntiles;
+  const int rblock = tile / P.uW;
+  const int wc = tile - rblock * P.uW;
+  const int lev0 = lchunk * P.wpb; // wpb: levels per chunk
+  const int lev1 = (lev0 + P.wpb < P.nlev) ? lev0 + P.wpb : P.nlev;
+  const int nx = P.nx, ny = P.ny;
+  const int first = 1 + rblock * TR; // rows 1 .. ny-2 are computed
+  const int col = wc * 256 + lane * 4;
+  const bool act = col < nx;
+  const int col_c = act ? col : nx - 4;
+  int east_col = wc * 256 + 256;
+  if (east_col > nx)
+    east_col = nx;
+
+  if (wave >= TR) {
+    // ------------------------------------------------------------------ loader
+    const int lw = wave - TR;
+    int off[KMAX], slot_of[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int s = lw + NL * k;
+      if (s > NS - 1)
+        s = NS - 1; // a wave with fewer rows repeats the last slot (same data to the same place)
+      const int jr = first + s - 1;
+      const int j = jr < ny - 1 ? jr : ny - 1; // rows past the field: the last row, never used
+      slot_of[k] = s;
+      off[k] = j * nx + col_c; // offsets inside a level fit 32 bits (the launcher checks)
+    }
+    // edge scalars: lane i gathers (slot i / 2, side i % 2); lanes past 2 NS repeat lane 0's
+    const int ei = (lane < 2 * NS) ? lane : 0;
+    const int ejr = first + (ei >> 1) - 1;
+    const int ej = ejr < ny - 1 ? ejr : ny - 1;
+    long e64 = (long)ej * nx + ((ei & 1) ? east_col : (wc * 256 - 1));
+    const long idx_hi = (long)nx * ny - 1;
+    e64 = e64 < 0 ? 0 : (e64 > idx_hi ? idx_hi : e64);
+    const int eoff = (int)e64;
+
+    // The wait count of the loop is an immediate, so a loader that also gathers the edge scalars (loader 0 of the
+    // operators that read x-neighbours) runs its own copy of the loop.
+    auto walk = [&](auto edge_tag) __attribute__((always_inline)) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
+      constexpr int L = KMAX + (EDGE ? 1 : 0); // load instructions per level of this wave
+      auto issue = [&](int lev, int b) {
+        const int l = lev < lev1 ? lev : lev1 - 1; // past the chunk: a valid address into a buffer nobody reads
+        const float* __restrict__ f = P.f + (size_t)l * P.in_stride;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(f + off[k]),
+                                           (void __attribute__((address_space(3)))*)&srow[b][slot_of[k]][0], 16, 0, 0);
+        if (EDGE)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(f + eoff), (void __attribute__((address_space(3)))*)&sedge[b][0],
+                                           4, 0, 0);
+      };
+#pragma unroll
+      for (int k = 0; k < PF; ++k)
+        issue(lev0 + k, k);
+      int b_next = PF % NB; // buffer of level lev + PF
+      // the last loader hands a level's undefined count to the global counter one level late: it idles between its loads
+      // and the next barrier anyway.  Its atomic is one more entry in this wave's vmcnt queue, younger than the loads the
+      // next wait is about: that wait can only get stricter.
+      auto hand_over = [&](int lev_done) {
+        if (CHECK && lw == NL - 1 && P.n_undefined && lane == 0) {
+          const int q = (lev_done - lev0) & 1;
+          const unsigned int n = sbad[q];
+          if (n != 0) {
+            atomicAdd(P.n_undefined + lev_done, (u64)n);
+            sbad[q] = 0; // the next adds into this slot come after the next barrier, which this wave reaches with lgkmcnt(0)
+          }
+        }
+      };
+      for (int lev = lev0; lev < lev1; ++lev) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((PF - 1) * L) : "memory"); // level lev has landed
+        issue(lev + PF, b_next); // into the buffer of level lev - 1, whose readers all passed the barrier above
+        b_next = (b_next + 1 == NB) ? 0 : b_next + 1;
+        if (lev > lev0)
+          hand_over(lev - 1); // complete since the barrier above
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land in LDS after the workgroup has gone
+      if (CHECK) {
+        asm volatile("s_barrier" ::: "memory"); // the compute waves' last barrier
+        if (lev1 > lev0)
+          hand_over(lev1 - 1);
+      }
+    };
+    if (NEED_X && lw == 0)
+      walk(std::true_type());
+    else
+      walk(std::false_type());
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute
+  const int slot = wave + 1;
+  const int j_raw = first + wave;
+  const bool computes = j_raw <= ny - 2;
+  const int j = computes ? j_raw : ny - 2;
+  const float undef = P.undef;
+  const int base = j * nx;
+  const int o = base + col_c;
+  const int oo = base + col;
+  const bool top = j == 1, bottom = j == ny - 2;
+  const bool last_in_seg = col + 4 >= east_col;
+  // the tile's map factors and Coriolis parameter: once, for every level of the chunk -- and with them everything of the
+  // point formula that does not depend on the level (ScalarHoist, mifc_scalar_cell.h)
+  ScalarHoist<OP> H;
+  {
+    v4f xm4 = {1.f, 1.f, 1.f, 1.f}, ym4 = xm4, fc4 = xm4;
+    if (computes) {
+      if (USE_XM)
+        xm4 = ld4(P.xm + o);
+      if (USE_YM)
+        ym4 = ld4(P.ym + o);
+      if (USE_FC)
+        fc4 = ld4(P.fc + o);
+    }
+    H.init(xm4, ym4, fc4);
+  }
+  // the one-sided gradients: one multiplication per partial where every lane's halved map factors are exact (wave-uniform,
+  // decided once per chunk; scalar_cell_hoisted), the general half_prod otherwise -- two copies of the walk
+  constexpr bool USES_HALF = (OP == ST_GRAD_X || OP == ST_GRAD_Y || OP == ST_GRAD_ABS);
+  const bool halves = USES_HALF && __builtin_amdgcn_ballot_w64(!H.halves_exact) == 0;
+  auto walk_levels = [&](auto halves_tag) __attribute__((always_inline)) {
+  constexpr bool HALVES = decltype(halves_tag)::value;
+  int buf = 0;
+  for (int lev = lev0; lev < lev1; ++lev) {
+    // the LDS reads of the previous level are consumed (their values went into the stores); stores stay in flight.  The
+    // level's input flag comes through the scalar cache with the barrier's own wait: a vector load of it would sit in this
+    // wave's vmcnt queue behind all those stores (level_flag_then_barrier, mifc_device.h)
+    bool all = true;
+    if (CHECK)
+      all = level_flag_then_barrier(P.all_defined, lev);
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (computes) {
+      const v4f fcur = srow[buf][slot][lane];
+      const v4f fn = srow[buf][slot + 1][lane], fs = srow[buf][slot - 1][lane];
+      float fW = fcur.x, fE = fcur.w;
+      if (NEED_X) {
+        const float We = sedge[buf][2 * slot], Ee = sedge[buf][2 * slot + 1];
+        fW = dpp_lower(We, fcur.w); // lane 0 keeps the west scalar
+        fE = dpp_upper(Ee, fcur.x); // lane 63 keeps the east scalar
+        if (last_in_seg)
+          fE = Ee;
+      }
+      const float fc6[6] = {fW, fcur.x, fcur.y, fcur.z, fcur.w, fE};
+      float z0[4], z1[4];
+      unsigned int bad = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float r0 = undef, r1 = undef;
+        const bool ok = scalar_cell_hoisted<OP, CHECK, HALVES>(all, undef, fc6[k], fc6[k + 1], fc6[k + 2], fs[k], fn[k], H, k, r0, r1);
+        z0[k] = ok ? r0 : undef;
+        z1[k] = ok ? r1 : undef;
+        if (CHECK)
+          bad += (!ok & act) ? 1u : 0u;
+      }
+      if (col == 0) { // fillEdges, column part (:65-68)
+        z0[0] = z0[1];
+        z1[0] = z1[1];
+      }
+      if (col + 4 == nx) {
+        z0[3] = z0[2];
+        z1[3] = z1[2];
+      }
+      if (act) {
+        float* o0p = P.o0 + (size_t)lev * P.out_stride;
+        st4_stream(o0p + oo, z0);
+        if (top) // fillEdges, row part (:70-73)
+          st4_stream(o0p + oo - nx, z0);
+        if (bottom)
+          st4_stream(o0p + oo + nx, z0);
+        if (TWO_OUT) {
+          float* o1p = P.o1 + (size_t)lev * P.out_stride;
+          st4_stream(o1p + oo, z1);
+          if (top)
+            st4_stream(o1p + oo - nx, z1);
+          if (bottom)
+            st4_stream(o1p + oo + nx, z1);
+        }
+      }
+      if (CHECK && P.n_undefined && !all && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+        const unsigned int n = wave_sum(bad);
+        if (lane == 0)
+          atomicAdd(&sbad[(lev - lev0) & 1], n);
+      }
+    }
+    buf = (buf + 1 == NB) ? 0 : buf + 1;
+  }
+  };
+  if (USES_HALF && halves)
+    walk_levels(std::true_type());
+  else
+    walk_levels(std::false_type());
+  if (CHECK) // the last level's adds are complete: the last loader hands its total over
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+struct SplitShape
+{
+  int tr, nl, pf, lg; // tile rows, loader waves, levels the loaders run ahead, levels per chunk (0: chosen from the batch)
+};
+
+int shape_value(const char* s, const char* key, int dflt)
+{
+  const size_t n = std::strlen(key);
+  for (const char* p = s; p && *p;) {
+    if (std::strncmp(p, key, n) == 0 && p[n] == '=')
+      return std::atoi(p + n + 1);
+    p = std::strchr(p, ',');
+    if (p)
+      ++p;
+  }
+  return dflt;
+}
+
+// Two shapes, chosen per operator and variant (profiles/r03/split_role_ops.txt, wave_placement.txt, sq_counters_split_shapes.txt):
+//   * {12 rows, 2 loaders, 3 levels ahead}: 14-wave workgroups.  Two of them would fit a CU by every resource, but the
+//     hardware keeps ONE resident (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE is 46 % of the 16-wave shapes'; workgroups of 13, 14 and
+//     15 waves all behave so, 12 and 16 do not) -- which suits the operators bound by memory: one workgroup per CU streaming
+//     three levels ahead is the access pattern of the headline kernel, 2-5 % faster than two workgroups per CU.
+//   * {14 rows, 2 loaders, 2 levels ahead}: 16-wave workgroups, two per CU, for the variants bound by instruction issue --
+//     |grad f| (a correctly rounded square root) and everything that tests its inputs but ilevelgwind and d/dy, whose
+//     arithmetic phases then overlap (the 14-wave shape runs them 15-25 % slower).
+// MIFC_SCALAR_SPLIT_TUNE="TR=12,NL=2,PF=2,LG=6" overrides (A/B measurements and tests; only the shapes instantiated below exist).
+SplitShape current_shape(int op, bool check)
+{
+  const bool issue_bound = op == ST_GRAD_ABS || (check && op != ST_IGWIND && op != ST_GRAD_Y);
+  SplitShape sh = issue_bound ? SplitShape{14, 2, 2, 0} : SplitShape{12, 2, 3, 0};
+  const char* s = env().scalar_split_tune;
+  if (s[0]) {
+    sh.tr = shape_value(s, "TR", sh.tr);
+    sh.nl = shape_value(s, "NL", sh.nl);
+    sh.pf = shape_value(s, "PF", sh.pf);
+    sh.lg = shape_value(s, "LG", sh.lg);
+  }
+  return sh;
+}
+
+template <int OP, int TR, int NL, int PF>
+void launch_shape(const SRowsParams& rp, bool check, int grid, hipStream_t stream)
+{
+  if (check)
+    hipLaunchKernelGGL((scalar_split_kernel<OP, true, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
+  else
+    hipLaunchKernelGGL((scalar_split_kernel<OP, false, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
+}
+
+// the instantiated shapes: {tile rows, loader waves, levels ahead}
+#define MIFC_SPLIT_SHAPES(X) X(12, 2, 3) X(14, 2, 2) X(12, 2, 2) X(12, 4, 2) X(10, 2, 2) X(8, 2, 2) X(12, 2, 1) X(13, 3, 2)
+
+bool shape_exists(const SplitShape& sh)
+{
+#define X(TR_, NL_, PF_) \
+  if (sh.tr == TR_ && sh.nl == NL_ && sh.pf == PF_) \
+    return true;
+  MIFC_SPLIT_SHAPES(X)
+#undef X
+  return false;
+}
+
+template <int OP>
+void launch_op(const SRowsParams& rp, const SplitShape& sh, bool check, int grid, hipStream_t stream)
+{
+#define X(TR_, NL_, PF_) \
+  if (sh.tr == TR_ && sh.nl == NL_ && sh.pf == PF_) { \
+    launch_shape<OP, TR_, NL_, PF_>(rp, check, grid, stream); \
+    return; \
+  }
+  MIFC_SPLIT_SHAPES(X)
+#undef X
+}
+
+// tiles x level chunks of the launch
+bool plan(const SplitShape& sh, int nx, int ny, int nlev, int* levels_per_chunk, long* units)
+{
+  if (nlev < 3 || (long)nx * ny >= 0x7fffffffL)
+    return false;
+  const int target = sh.lg > 0 ? sh.lg : (nlev >= 48 ? 6 : 8); // levels per chunk; the chunks are then balanced
+  const int nchunks = (nlev + target - 1) / target;
+  const int lpc = (nlev + nchunks - 1) / nchunks;
+  const long tiles = (long)((ny - 2 + sh.tr - 1) / sh.tr) * ((nx + 255) / 256);
+  *levels_per_chunk = lpc;
+  *units = tiles * ((nlev + lpc - 1) / lpc);
+  return *units <= 0x3fffffffL;
+}
+
+} // namespace
+
+bool scalar_split_applies(int op, int nx, int ny, int nlev, bool check, float undef)
+{
+  if (!env().split_roles || !env().levelwalk || op < ST_GRAD_X || op > ST_IGWIND)
+    return false;
+  if (check && undef != undef) // the kernel tests with ONE compare per value, which is is_def() only for an undef that is not NaN
+    return false;
+  const SplitShape sh = current_shape(op, check);
+  int lpc;
+  long units;
+  if (!shape_exists(sh) || !plan(sh, nx, ny, nlev, &lpc, &units))
+    return false;
+  return units >= (env().levelwalk_min_units > 0 ? env().levelwalk_min_units : 768);
+}
+
+hipError_t launch_scalar_split(int op, SRowsParams& rp, bool check, hipStream_t stream)
+{
+  const SplitShape sh = current_shape(op, check);
+  int lpc;
+  long units;
+  if (!shape_exists(sh) || !plan(sh, rp.nx, rp.ny, rp.nlev, &lpc, &units))
+    return hipErrorInvalidValue; // scalar_split_applies() said otherwise
+  rp.uB = (rp.ny - 2 + sh.tr - 1) / sh.tr;
+  rp.uW = (rp.nx + 255) / 256;
+  rp.wpb = lpc;
+  rp.n_logical = (int)units;
+  rp.per_xcd = (rp.n_logical + 7) / 8;
+  const int grid = rp.per_xcd * 8;
+  switch (op) {
+  case ST_GRAD_X:
+    launch_op<ST_GRAD_X>(rp, sh, check, grid, stream);
+    break;
+  case ST_GRAD_Y:
+    launch_op<ST_GRAD_Y>(rp, sh, check, grid, stream);
+    break;
+  case ST_GRAD_ABS:
+    launch_op<ST_GRAD_ABS>(rp, sh, check, grid, stream);
+    break;
+  case ST_GRAD_LAP:
+    launch_op<ST_GRAD_LAP>(rp, sh, check, grid, stream);
+    break;
+  case ST_GWIND_X:
+    launch_op<ST_GWIND_X>(rp, sh, check, grid, stream);
+    break;
+  case ST_GWIND_Y:
+    launch_op<ST_GWIND_Y>(rp, sh, check, grid, stream);
+    break;
+  case ST_GVORT:
+    launch_op<ST_GVORT>(rp, sh, check, grid, stream);
+    break;
+  default:
+    launch_op<ST_IGWIND>(rp, sh, check, grid, stream);
+    break;
+  }
+  return hipGetLastError();
+}
+
+} // namespace mifc

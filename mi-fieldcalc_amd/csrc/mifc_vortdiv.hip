@@ -925,7 +925,13 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
       // above and the stores of the previous levels stay in flight across the barrier.  Two buffers: a wave
       // can only overwrite buffer b again after the barrier of the level in between, which every wave reaches
       // with its reads of b consumed.
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // (the level's input flag through the scalar cache, with the same wait: a vector load of the byte would be the
+      // youngest entry of this wave's vmcnt queue, and waiting for it would drain the prefetch and every store in flight)
+      bool all = true;
+      if (CHECK)
+        all = level_flag_then_barrier(P.all_defined, lev);
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (CHECK && P.n_undefined && threadIdx.x == 0 && lev > lev0) { // the count of the previous level is complete
         const int q = (lev - 1 - lev0) & 1;
         const unsigned int n = sbad[q];
@@ -935,7 +941,6 @@ __global__ __launch_bounds__(64 * NW, (HALO && PF == 1) ? (NW == 12 ? 6 : 8) : 1
         }
       }
       if (computes) {
-        const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
         // two passes, vorticity then divergence, each taking its rows from LDS when it needs them and storing at
         // once: fewer live registers than one fused pass (the variant with tests spilled otherwise)
         const v4f uc = C.u, vc = C.v;
@@ -1057,9 +1062,14 @@ chunk_done:;
 //       computes: level lev from buffer t % (PF + 1)
 // A loader wave issues the same number L of load instructions for every level (a wave with fewer rows repeats its last
 // one), so that the wait count is an immediate; loader 0, which also gathers the edge scalars, has its own copy of the loop.
-template <bool CHECK, bool NT, int TR, int NL, int PF>
+// WANT_V / WANT_D: which of the two results the launch produces (relvort or divergence alone read the very same rows:
+// 12 instead of 16 B per cell); ABSV: the vorticity gets the tile's Coriolis parameter added (absvort, :1896), which
+// lives in registers next to the map factors for the whole walk.
+template <bool CHECK, bool NT, int TR, int NL, int PF, bool WANT_V = true, bool WANT_D = true, bool ABSV = false>
 __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const RowsParams P)
 {
+  static_assert(WANT_V || WANT_D, "nothing to compute");
+  static_assert(!ABSV || (WANT_V && !WANT_D), "absvort is a single-output operator");
   constexpr int NB = PF + 1;                // level buffers
   constexpr int NS = TR + 2;                // row slots per level: slot s holds tile row s - 1
   constexpr int KMAX = (NS + NL - 1) / NL;  // row slots per loader wave
@@ -1159,7 +1169,8 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
         }
       };
       for (int lev = lev0; lev < lev1; ++lev) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PF - 1) * L) : "memory");
+        // lgkmcnt(0): the reset of a count slot below (a ds_write) has landed before the compute waves add into it again
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((PF - 1) * L) : "memory");
         issue(lev + PF, b_next);
         b_next = (b_next + 1 == NB) ? 0 : b_next + 1;
         if (lev > lev0)
@@ -1192,17 +1203,24 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
   const bool bottom = (j == P.nyg - 2) && (P.j0 + P.ny_local == P.nyg);
   const bool last_in_seg = col + 4 >= east_col;
   const int oo = base + col;
-  v4f xm4 = {0.f, 0.f, 0.f, 0.f}, ym4 = xm4;
+  v4f xm4 = {0.f, 0.f, 0.f, 0.f}, ym4 = xm4, fc4 = xm4;
   if (computes) { // the tile's map factors: once, for every level of the chunk
     xm4 = load4(P.xm + o);
     ym4 = load4(P.ym + o);
+    if constexpr (ABSV)
+      fc4 = load4(P.fc + o);
   }
   int buf = 0;
   for (int lev = lev0; lev < lev1; ++lev) {
-    // the LDS reads of the previous level are consumed (their values went into the stores); stores stay in flight
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // the LDS reads of the previous level are consumed (their values went into the stores); stores stay in flight.  The
+    // level's input flag comes through the scalar cache with the barrier's own wait: a vector load of it would sit in this
+    // wave's vmcnt queue behind all those stores (level_flag_then_barrier, mifc_device.h)
+    bool all = true;
+    if (CHECK)
+      all = level_flag_then_barrier(P.all_defined, lev);
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (computes) {
-      const bool all = CHECK ? (P.all_defined && P.all_defined[lev] != 0) : true;
       const v4f uc = srow[buf][slot][0][lane], vc = srow[buf][slot][1][lane];
       const float uWe = sedge[buf][4 * slot + 0], uEe = sedge[buf][4 * slot + 1];
       const float vWe = sedge[buf][4 * slot + 2], vEe = sedge[buf][4 * slot + 3];
@@ -1214,7 +1232,7 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
       }
       bool ok[4] = {true, true, true, true};
       unsigned int bad = 0;
-      {
+      if constexpr (WANT_V || CHECK) { // divergence alone still tests the vorticity's four values (:1927)
         const v4f un = srow[buf][slot + 1][0][lane], us = srow[buf][slot - 1][0][lane];
         const float vcx[6] = {vW, vc.x, vc.y, vc.z, vc.w, vE};
         float zv[4];
@@ -1233,30 +1251,34 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
           const float vw = vcx[k], ve = vcx[k + 2];
           if (CHECK) // both operators test these four values (:1861, :1927)
             ok[k] = all | (dvx[k] & dvx[k + 2] & (bool)__builtin_islessgreater(us[k], undef) & (bool)__builtin_islessgreater(un[k], undef));
-          const float z = f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
-          zv[k] = ok[k] ? z : undef;
+          if constexpr (WANT_V) {
+            const float z = ABSV ? f_absvort(xm4[k], ym4[k], ve - vw, un[k] - us[k], fc4[k]) : f_relvort(xm4[k], ym4[k], ve - vw, un[k] - us[k]);
+            zv[k] = ok[k] ? z : undef;
+          }
           if (CHECK)
             bad += (!ok[k] & act) ? 1u : 0u;
         }
-        if (col == 0) // fillEdges, column part (:65-68)
-          zv[0] = zv[1];
-        if (col + 4 == nx)
-          zv[3] = zv[2];
-        if (act) {
-          float* rv = P.rv + (size_t)lev * P.out_stride;
-          v4f z4;
-          z4.x = zv[0];
-          z4.y = zv[1];
-          z4.z = zv[2];
-          z4.w = zv[3];
-          store4<NT>(rv + oo, z4);
-          if (top) // fillEdges, row part (:70-73)
-            store4<NT>(rv + oo - nx, z4);
-          if (bottom)
-            store4<NT>(rv + oo + nx, z4);
+        if constexpr (WANT_V) {
+          if (col == 0) // fillEdges, column part (:65-68)
+            zv[0] = zv[1];
+          if (col + 4 == nx)
+            zv[3] = zv[2];
+          if (act) {
+            float* rv = P.rv + (size_t)lev * P.out_stride;
+            v4f z4;
+            z4.x = zv[0];
+            z4.y = zv[1];
+            z4.z = zv[2];
+            z4.w = zv[3];
+            store4<NT>(rv + oo, z4);
+            if (top) // fillEdges, row part (:70-73)
+              store4<NT>(rv + oo - nx, z4);
+            if (bottom)
+              store4<NT>(rv + oo + nx, z4);
+          }
         }
       }
-      {
+      if constexpr (WANT_D) {
         const v4f vn = srow[buf][slot + 1][1][lane], vs = srow[buf][slot - 1][1][lane];
         const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
         float zd[4];
@@ -1486,6 +1508,9 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   if (env().force_cell_kernel)
     return hipSuccess;
 
+  // the split-role kernel's tests are ONE compare per value ("ordered and != undef"), which is is_def() only for an
+  // undef that is not NaN: a NaN undef takes the kernels with the generic two-compare test
+  const bool nan_undef_tested = !prm.every_level_all_defined && prm.undef != prm.undef;
   Tuning t = current_tuning(nx);
   while (t.WPB > 1 && t.WPB / 2 >= prm.nlev)
     t.WPB /= 2; // fewer levels than waves: do not launch waves that only stage map factors
@@ -1504,7 +1529,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       // (profiles/r01/other_configs.jsonl, cold numbers).
       t.K = (small || prm.op == ST_JACOBIAN) ? 1 : 2;
     }
-    else if (prm.op != ST_JACOBIAN && prm.op != ST_ABSVORT && prm.nlev >= kLevelWalkMinLevels && env().levelwalk) {
+    else if (prm.op != ST_JACOBIAN && (prm.op != ST_ABSVORT || (env().split_roles && !nan_undef_tested)) && prm.nlev >= kLevelWalkMinLevels && env().levelwalk) {
       // Deep batches: tiles that stay put and walk the levels (map factors once per chunk of levels, a narrow
       // window of each array open at any time).  12-wave workgroups, 10 computed rows + 2 halo waves, chunks of
       // about 6 levels (8 in shallower batches), balanced; 3-6 % faster than the row-walking kernel on every device tried
@@ -1518,11 +1543,14 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         t.ZZ = 1;
         t.D = 0;
         t.LG = (prm.nlev + nchunks - 1) / nchunks;
-        // The fused pair: the same tiles with split roles -- 2 loader waves bring 14 rows of u and v straight into LDS
-        // two levels ahead, 12 compute waves only read LDS and store (vortdiv_split_kernel).  1-5 % faster than the
+        // The same tiles with split roles -- 2 loader waves bring 14 rows of u and v straight into LDS two levels
+        // ahead, 12 compute waves only read LDS and store (vortdiv_split_kernel).  The fused pair: 1-5 % faster than the
         // form above on every box, placement and shape tried, 4 % on the tested variant, up to 18 % on shallow batches
-        // (profiles/r02/experiments/sweep_k4_*.txt, ab_split_roles.txt).
-        if (rv && dv && env().split_roles) {
+        // (profiles/r02/experiments/sweep_k4_*.txt, ab_split_roles.txt).  Round 3: absvort too (+2 % on the row-walking
+        // kernel it ran before, which has no level-walking form of the first kind); relvort / divergence ALONE measure
+        // the same in both forms (12 B per cell: +-1 %, the sign depends on the box -- profiles/r03/split_role_ops.txt) and
+        // keep the first, MIFC_VORTDIV_TUNE="K=4,..." selects the split-role one.
+        if (env().split_roles && !nan_undef_tested && ((rv && dv) || prm.op == ST_ABSVORT)) {
           t.K = 4;
           t.D = 1;
           t.WPB = 2;
@@ -1616,6 +1644,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       }
       return hipGetLastError();
     }
+    *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
+    return hipSuccess;
   }
   if (t.K == 1 && prm.op == ST_JACOBIAN) { // one-shot form of the Jacobian
     rp.uB = (rp.hi - rp.lo + 3) / 4;
@@ -1631,6 +1661,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         hipLaunchKernelGGL((vortdiv_oneshot_kernel<true, true, false, true, true>), dim3(grid), dim3(256), 0, stream, rp);
       return hipGetLastError();
     }
+    *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
+    return hipSuccess;
   }
   if (t.K == 1 && !rp.fc && prm.op != ST_JACOBIAN) { // one-shot form: units are (level, block of 4 rows, 256-column segment)
     rp.uB = (rp.hi - rp.lo + 3) / 4;
@@ -1665,10 +1697,14 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       }
       return hipGetLastError();
     }
+    *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
+    return hipSuccess;
   }
-  if (t.K == 4 && !prm.every_level_all_defined && prm.undef != prm.undef) {
-    // the split-role kernel's tests are ONE compare per value ("ordered and != undef"), which is is_def() only for an
-    // undef that is not NaN: a NaN undef takes the level-walking kernel with the generic test
+  if (t.K == 4 && nan_undef_tested) { // only a forced tuning gets here: the default selection above never picks K = 4 for these
+    if (rp.fc) { // absvort has no other level-walking form: leave the request to the flat kernel
+      *handled = false;
+      return hipSuccess;
+    }
     t.K = 3;
     t.D = 0;
     t.WPB = 8;
@@ -1695,6 +1731,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         hipLaunchKernelGGL((vortdiv_levelwalk_kernel<false, false, true, true, NW, 1, true>), dim3(grid), dim3(64 * NW), 0, stream, rp);
       return hipGetLastError();
     }
+    *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
+    return hipSuccess;
   }
   if (t.K == 3 && !rp.fc && prm.op != ST_JACOBIAN && rv && dv) { // level-walking tiles: units are (level chunk, row block, 256-column segment)
     const int NWsel = (t.RB == 16 || t.RB == 12 || t.RB == 8) ? t.RB : 16; // RB doubles as the waves per workgroup here
@@ -1736,46 +1774,65 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
 #undef LEVELWALK
       return hipGetLastError();
     }
+    *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
+    return hipSuccess;
   }
-  if (t.K == 4 && !rp.fc && prm.op != ST_JACOBIAN && rv && dv) { // split-role level-walking tiles (loader waves / compute waves)
-    const int tile_rows = (t.RB == 6 || t.RB == 8 || t.RB == 12 || t.RB == 14) ? t.RB : 10;
+  if (t.K == 4 && prm.op != ST_JACOBIAN) { // split-role level-walking tiles (loader waves / compute waves)
+    const bool single = !(rv && dv) || rp.fc; // one output: the default shape only (and its one-level-ahead sibling)
+    const int tile_rows = single ? 12 : ((t.RB == 6 || t.RB == 8 || t.RB == 12 || t.RB == 14) ? t.RB : 10);
+    const int nchunks_lg = (t.LG > 0 && t.LG < prm.nlev) ? t.LG : prm.nlev; // levels per workgroup
+    const int nchunks = (prm.nlev + nchunks_lg - 1) / nchunks_lg;
+    const long units = (long)nchunks * ((rp.hi - rp.lo + tile_rows - 1) / tile_rows) * ((nx + 255) / 256);
+    if (units > 0x3fffffffL || (long)nx * (rp.ny_local + 2) >= 0x7fffffffL) { // 32-bit offsets inside a level: not this kernel's case
+      *handled = false;
+      return hipSuccess;
+    }
     rp.uB = (rp.hi - rp.lo + tile_rows - 1) / tile_rows;
     rp.uW = (nx + 255) / 256;
-    rp.lgroup = (t.LG > 0 && t.LG < prm.nlev) ? t.LG : prm.nlev; // levels per workgroup
-    const int nchunks = (prm.nlev + rp.lgroup - 1) / rp.lgroup;
-    const long units = (long)nchunks * rp.uB * rp.uW;
-    if (units <= 0x3fffffffL && (long)nx * (rp.ny_local + 2) < 0x7fffffffL) {
-      rp.n_logical = (int)units;
-      rp.per_xcd = (rp.n_logical + 7) / 8;
-      grid = rp.per_xcd * 8;
-      const bool chk = !prm.every_level_all_defined;
-      const int pf = t.D >= 2 ? 3 : (t.D == 1 ? 2 : 1); // D selects how many levels the loaders run ahead
-      const int nl = (t.WPB == 2 || t.WPB == 4) ? t.WPB : (tile_rows == 10 ? 4 : 2); // WPB doubles as the number of loader waves
-#define SPLIT(TR_, NL_, PF_)                                                                                                          \
-  if (chk)                                                                                                                            \
-    hipLaunchKernelGGL((vortdiv_split_kernel<true, true, TR_, NL_, PF_>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp);          \
-  else                                                                                                                                \
-    hipLaunchKernelGGL((vortdiv_split_kernel<false, true, TR_, NL_, PF_>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp)
-      if (tile_rows == 6) {
-        if (pf == 3) { SPLIT(6, 2, 3); } else if (pf == 2) { SPLIT(6, 2, 2); } else { SPLIT(6, 2, 1); }
-      } else if (tile_rows == 8) {
-        if (pf == 3) { SPLIT(8, 2, 3); } else if (pf == 2) { SPLIT(8, 2, 2); } else { SPLIT(8, 2, 1); }
-      } else if (tile_rows == 12 && nl == 4) {
-        if (pf >= 2) { SPLIT(12, 4, 2); } else { SPLIT(12, 4, 1); }
-      } else if (tile_rows == 12) {
-        if (pf == 3) { SPLIT(12, 2, 3); } else if (pf == 2) { SPLIT(12, 2, 2); } else { SPLIT(12, 2, 1); }
-      } else if (tile_rows == 14) { // 16 waves: two loaders at most
-        if (pf >= 2) { SPLIT(14, 2, 2); } else { SPLIT(14, 2, 1); }
-      } else if (nl == 2) {
-        if (pf >= 2) { SPLIT(10, 2, 2); } else { SPLIT(10, 2, 1); }
+    rp.lgroup = nchunks_lg;
+    rp.n_logical = (int)units;
+    rp.per_xcd = (rp.n_logical + 7) / 8;
+    grid = rp.per_xcd * 8;
+    const bool chk = !prm.every_level_all_defined;
+    const int pf = t.D >= 2 ? 3 : (t.D == 1 ? 2 : 1); // D selects how many levels the loaders run ahead
+    const int nl = (t.WPB == 2 || t.WPB == 4) ? t.WPB : (tile_rows == 10 ? 4 : 2); // WPB doubles as the number of loader waves
+#define SPLIT_AS(TR_, NL_, PF_, ...)                                                                                                       \
+  if (chk)                                                                                                                                 \
+    hipLaunchKernelGGL((vortdiv_split_kernel<true, true, TR_, NL_, PF_, ##__VA_ARGS__>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp); \
+  else                                                                                                                                     \
+    hipLaunchKernelGGL((vortdiv_split_kernel<false, true, TR_, NL_, PF_, ##__VA_ARGS__>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp)
+    if (single) {
+      const bool pf1 = pf == 1;
+      if (rp.fc) {
+        if (pf1) { SPLIT_AS(12, 2, 1, true, false, true); } else { SPLIT_AS(12, 2, 2, true, false, true); }
+      } else if (rv) {
+        if (pf1) { SPLIT_AS(12, 2, 1, true, false, false); } else { SPLIT_AS(12, 2, 2, true, false, false); }
       } else {
-        if (pf == 3) { SPLIT(10, 4, 3); } else if (pf == 2) { SPLIT(10, 4, 2); } else { SPLIT(10, 4, 1); }
+        if (pf1) { SPLIT_AS(12, 2, 1, false, true, false); } else { SPLIT_AS(12, 2, 2, false, true, false); }
       }
-#undef SPLIT
       return hipGetLastError();
     }
+#define SPLIT(TR_, NL_, PF_) SPLIT_AS(TR_, NL_, PF_)
+    if (tile_rows == 6) {
+      if (pf == 3) { SPLIT(6, 2, 3); } else if (pf == 2) { SPLIT(6, 2, 2); } else { SPLIT(6, 2, 1); }
+    } else if (tile_rows == 8) {
+      if (pf == 3) { SPLIT(8, 2, 3); } else if (pf == 2) { SPLIT(8, 2, 2); } else { SPLIT(8, 2, 1); }
+    } else if (tile_rows == 12 && nl == 4) {
+      if (pf >= 2) { SPLIT(12, 4, 2); } else { SPLIT(12, 4, 1); }
+    } else if (tile_rows == 12) {
+      if (pf == 3) { SPLIT(12, 2, 3); } else if (pf == 2) { SPLIT(12, 2, 2); } else { SPLIT(12, 2, 1); }
+    } else if (tile_rows == 14) { // 16 waves: two loaders at most
+      if (pf >= 2) { SPLIT(14, 2, 2); } else { SPLIT(14, 2, 1); }
+    } else if (nl == 2) {
+      if (pf >= 2) { SPLIT(10, 2, 2); } else { SPLIT(10, 2, 1); }
+    } else {
+      if (pf == 3) { SPLIT(10, 4, 3); } else if (pf == 2) { SPLIT(10, 4, 2); } else { SPLIT(10, 4, 1); }
+    }
+#undef SPLIT
+#undef SPLIT_AS
+    return hipGetLastError();
   }
-  if (t.K == 2 && !rp.fc && prm.op != ST_JACOBIAN && t.RB == 14) { // one-shot tiles of 14 rows (16-wave workgroups)
+  if (t.K == 2 && !rp.fc && prm.op != ST_JACOBIAN && t.RB == 14 && rv && dv) { // one-shot tiles of 14 rows (16-wave workgroups)
     constexpr int RB = 14;
     rp.uB = (rp.hi - rp.lo + RB - 1) / RB;
     rp.uW = (nx + 255) / 256;
@@ -1784,13 +1841,14 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       rp.n_logical = (int)units;
       rp.per_xcd = (rp.n_logical + 7) / 8;
       grid = rp.per_xcd * 8;
-      if (prm.every_level_all_defined && rv && dv)
+      if (prm.every_level_all_defined)
         hipLaunchKernelGGL((vortdiv_tile_kernel<false, true, true, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp);
-      else if (rv && dv)
+      else
         hipLaunchKernelGGL((vortdiv_tile_kernel<true, true, true, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp);
-      if (rv && dv)
-        return hipGetLastError();
+      return hipGetLastError();
     }
+    *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
+    return hipSuccess;
   }
   if (t.K == 2 && !rp.fc && prm.op != ST_JACOBIAN) { // one-shot tiles: units are (level, block of 8 rows, 256-column segment)
     constexpr int RB = 8;
@@ -1823,6 +1881,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       }
       return hipGetLastError();
     }
+    *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
+    return hipSuccess;
   }
   if (prm.op == ST_JACOBIAN) {
     if (t.V == 3)

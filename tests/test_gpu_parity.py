@@ -652,15 +652,24 @@ def test_headline_1440x720x137_properties(gpu_ctx, oracle, mifc_env):
 
 # ------------------------------------------------------------------ generic batched stencils
 @pytest.mark.parametrize("nx,ny,nlev", [(64, 48, 5), (260, 21, 4), (520, 25, 7), (1440, 13, 9), (8, 3, 3)])
-@pytest.mark.parametrize("walk", [None, "1"])
+@pytest.mark.parametrize("walk", [None, "1", "1/nosplit", "1/TR=12,NL=4,PF=2", "1/TR=14,NL=2,PF=2,LG=2", "1/TR=8,NL=2,PF=2,LG=3", "1/TR=12,NL=2,PF=3,LG=4",
+                                  "1/TR=12,NL=2,PF=1,LG=1", "1/TR=10,NL=2,PF=2", "1/TR=13,NL=3,PF=2,LG=5", "1/TR=12,NL=2,PF=2"])
 def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc_env):
     """mifc_stencil_levels: each operator over a batch == the per-level reference call, flags included.
     walk="1": the level-walking forms (tiles that stay put and walk the levels) are chosen whatever the launch
-    size -- ragged tiles, widths below one segment, chunks of unequal length; device-resident batches then."""
+    size -- ragged tiles, widths below one segment, chunks of unequal length; device-resident batches then.  By default
+    those are the split-role kernels (loader waves / compute waves) for every operator but the Jacobian; "1/nosplit" keeps
+    the forms whose waves load and store, "1/TR=..." other shapes of the one-input split-role kernel."""
     import torch
 
     import mi_fieldcalc_amd.synth as synth
 
+    if walk is not None and "/" in walk:
+        walk, how = walk.split("/")
+        if how == "nosplit":
+            mifc_env("MIFC_VORTDIV_SPLIT", "0")
+        else:
+            mifc_env("MIFC_SCALAR_SPLIT_TUNE", how)
     mifc_env("MIFC_LEVELWALK_MIN_UNITS", walk)
     on_device = walk is not None
     xm, ym, fcor = synth.grid_maps(nx, ny)
@@ -701,6 +710,87 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc
             if e1 is not None:
                 assert cases.same_bits(o1[l], e1, nan_payload=False), (name, l)
             assert fo[l] == f_e, (name, l, fo[l], f_e)
+
+
+def test_stencil_levels_enqueue_equals_the_synchronous_call(gpu_ctx, oracle):
+    """mifc_stencil_levels_enqueue (nothing read back; counts stay on the device) against mifc_stencil_levels: same fields bit
+    for bit, and classify(count, mifc_stencil_count_domain) gives the flags -- plevelgwind_xcomp excepted, which is
+    NONE_DEFINED whatever the count (FieldCalculations.cc:664).  Mixed flags per level; one call with every level
+    ALL_DEFINED and no counter array."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 516, 40, 6
+    xm, ym, fcor = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 31, nlev=nlev)
+    z = np.stack([synth.scalar_field(nx, ny, 900 + l) for l in range(nlev)])
+    flags = np.array([ALL, SOME, SOME, ALL, SOME, SOME], np.int32)
+    for l in (1, 4):
+        u[l] = synth.sprinkle_undef(u[l], 3 + l, 0.03)
+        z[l] = synth.sprinkle_undef(z[l], 13 + l, 0.03)
+    z[2] = cases.UNDEF
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    du, dv, dz, dxm, dym, dfc = (dev(a) for a in (u, v, z, xm, ym, fcor))
+    counts = torch.full((nlev,), 12345, dtype=torch.int64, device="cuda")
+    for name, f0, f1, use_fc in [("vortdiv", du, dv, False), ("relvort", du, dv, False), ("absvort", du, dv, True), ("gradient1", dz, None, False),
+                                 ("gradient3", dz, None, False), ("plevelgwind_xcomp", dz, None, True), ("plevelgvort", dz, None, True),
+                                 ("ilevelgwind", dz, None, True), ("jacobian", dz, du, False)]:
+        two = name in ("vortdiv", "ilevelgwind")
+        (e0, e1), fe = gpu_ctx.stencil_levels(name, f0, f1, dxm, dym, dfc if use_fc else None, fdefined=flags)
+        o0, o1 = torch.empty_like(du), (torch.empty_like(du) if two else None)
+        assert gpu_ctx.stencil_levels_enqueue(name, f0, f1, dxm, dym, dfc if use_fc else None, o0, o1, fdefined=flags, n_undefined=counts), name
+        torch.cuda.synchronize()
+        assert torch.equal(o0.view(torch.int32), e0.view(torch.int32)), name
+        if two:
+            assert torch.equal(o1.view(torch.int32), e1.view(torch.int32)), name
+        dom = gpu_ctx.stencil_count_domain(name, nx, ny)
+        got = [fc.NONE_DEFINED if name == "plevelgwind_xcomp" else fc.classify(int(c), dom) for c in counts.cpu().numpy()]
+        assert got == list(fe), (name, got, list(fe))
+    # every level ALL_DEFINED: no tests, no counters
+    clean_u, clean_v = synth.wind(nx, ny, 32, nlev=nlev)
+    o0 = torch.empty_like(du)
+    all_flags = np.full(nlev, ALL, np.int32)
+    assert gpu_ctx.stencil_levels_enqueue("divergence", dev(clean_u), dev(clean_v), dxm, dym, None, o0, fdefined=all_flags, n_undefined=None)
+    torch.cuda.synchronize()
+    for l in (0, nlev - 1):
+        ok, e, _ = oracle.call("divergence", nx, ny, clean_u[l], clean_v[l], xm, ym, fdefined=ALL)
+        assert ok and cases.same_bits(o0[l].cpu().numpy(), e, nan_payload=False)
+    # a tested call without a counter array is refused
+    with pytest.raises(RuntimeError, match="n_undefined_dev"):
+        gpu_ctx.stencil_levels_enqueue("divergence", du, dv, dxm, dym, None, o0, fdefined=flags, n_undefined=None)
+
+
+@pytest.mark.parametrize("tiny", ["some", "all", "none"])
+def test_gradients_with_map_factors_whose_halves_are_inexact(gpu_ctx, oracle, tiny, mifc_env):
+    """(float)(0.5 * m * d) of the one-sided gradients (FieldCalculations.cc:2015, :2027, :2040): the level-walking kernels
+    multiply by a pre-halved map factor where 0.5f * m is exact for every lane of a wave, and take the general route
+    (half_prod: halve the larger factor) otherwise.  Map factors below 2^-125 -- subnormal halves -- next to fields of
+    1e30 .. 1e38, so that the products are ordinary numbers and a wrongly halved factor shows; zeros and infinities too."""
+    import mi_fieldcalc_amd.synth as synth
+
+    mifc_env("MIFC_LEVELWALK_MIN_UNITS", "1")
+    nx, ny, nlev = 516, 31, 5
+    rng = np.random.default_rng(77)
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    small = np.array([1e-39, 2.0 ** -126, 3.0 * 2.0 ** -127, 2.0 ** -149, 1.1754942e-38, 2.0 ** -125, 0.0, -(2.0 ** -126), np.inf], np.float32)
+    if tiny != "none":
+        pick = rng.random((ny, nx)) < (0.05 if tiny == "some" else 1.0)
+        xm = np.where(pick, rng.choice(small, (ny, nx)), xm).astype(np.float32)
+        ym = np.where(pick.T.reshape(-1)[: nx * ny].reshape(ny, nx), rng.choice(small, (ny, nx)), ym).astype(np.float32)
+    z = (rng.standard_normal((nlev, ny, nx)) * 10.0 ** rng.uniform(30, 38, (nlev, ny, nx))).astype(np.float32)
+    flags = np.array([ALL, SOME, ALL, SOME, ALL], np.int32)
+    z[1] = synth.sprinkle_undef(z[1], 5, 0.02)
+    with np.errstate(all="ignore"):
+        for compute in (1, 2, 3):
+            res = gpu_ctx.stencil_levels("gradient%d" % compute, z, None, xm, ym, None, fdefined=flags)
+            assert res is not None
+            (o0, _), fo = res
+            for l in range(nlev):
+                ok, e, f_e = oracle.call("gradient", nx, ny, z[l], xm, ym, compute, fdefined=int(flags[l]))
+                assert ok and cases.same_bits(o0[l], e, nan_payload=False), (compute, l)
+                assert fo[l] == f_e, (compute, l)
 
 
 @pytest.mark.parametrize("nx,ny", [(64, 24), (1440, 37), (260, 9)])
