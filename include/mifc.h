@@ -423,6 +423,52 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int 
 int mifc_vortdiv_slab_rows_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int ny_local, int row_begin, int row_end, const float* u_halo,
                                    const float* v_halo, const float* xmapr, const float* ymapr, float* rvort, float* diverg, int fdefined_in,
                                    float undef, unsigned long long* n_undefined_dev, int accumulate_count);
+/* ---- the decomposed step as ONE call (BASELINE.json config 4) --------------- */
+/* Communicator: RCCL over xGMI, one process per GPU.  Either the library creates it -- rank 0 calls
+ * mifc_comm_unique_id(), the caller distributes the MIFC_COMM_ID_BYTES bytes to every rank by any means it
+ * has (MPI, a file, torch.distributed), every rank calls mifc_comm_init() -- or the caller hands over an
+ * ncclComm_t it already owns (mifc_comm_adopt: rank and size are read from it; e.g. PyTorch's
+ * ProcessGroupNCCL._comm_ptr()).  RCCL is loaded on first use; a process that never calls these never loads it.
+ * Slab k of a field lives on rank k: the neighbours of a slab are rank - 1 (above) and rank + 1 (below). */
+#define MIFC_COMM_ID_BYTES 128
+int mifc_comm_unique_id(char* id_out /* [MIFC_COMM_ID_BYTES] */);
+int mifc_comm_init(mifc_ctx* ctx, const char* id /* [MIFC_COMM_ID_BYTES] */, int rank, int world);
+int mifc_comm_adopt(mifc_ctx* ctx, void* nccl_comm);
+int mifc_comm_release(mifc_ctx* ctx);
+/* returns 1 when the context has a communicator; rank / world may be NULL */
+int mifc_comm_info(const mifc_ctx* ctx, int* rank, int* world);
+
+/* A plan binds the buffers of one rank's row slab of a level batch:
+ *   u_halo, v_halo : [nlev][ny_local + 2][nx], rows 1 .. ny_local of a level owned, rows 0 and ny_local + 1 its
+ *                    halo rows (filled by the step from the neighbours; never read at the edges of the whole field)
+ *   xmapr, ymapr   : [ny_local][nx] (owned rows, shared by the levels);  rvort, diverg : [nlev][ny_local][nx]
+ *   fdefined_in    : input state of every level (MIFC_ALL_DEFINED: no tests, no counters)
+ *   n_undefined_dev: device u64[nlev] (NULL allowed for MIFC_ALL_DEFINED)
+ * mifc_slab_plan_step() enqueues ONE decomposed step on the context's stream and returns: one row of u and of v per
+ * level to / from each neighbour (grouped ncclSend / ncclRecv on a stream of the plan's own), the owned rows that read
+ * no halo row meanwhile, then the two boundary strips, then -- tested input, more than one rank -- an ncclAllReduce
+ * that leaves the WHOLE field's undefined counts of every level in n_undefined_dev on every rank (classify against
+ * nx*ny_global - 2*nx; with one rank or MIFC_ALL_DEFINED nothing is reduced).  Results per level are bit-identical
+ * to relvort() + divergence() on the whole field (FieldCalculations.cc:1843-1940), fillEdges included.  The
+ * sequence is captured into a HIP graph on the first step and replayed afterwards (MIFC_SLAB_GRAPH=0, or a capture
+ * the runtime refuses: enqueued call by call); the buffers, the communicator and the tuning environment are those
+ * of the first step.  What the caller wrote to the owned rows of u_halo / v_halo on the context's stream before
+ * the call is what is sent. */
+typedef struct mifc_slab_plan mifc_slab_plan;
+mifc_slab_plan* mifc_slab_plan_create(mifc_ctx* ctx, int nx, int ny_global, int j0, int ny_local, int nlev, float* u_halo, float* v_halo,
+                                      const float* xmapr, const float* ymapr, float* rvort, float* diverg, int fdefined_in, float undef,
+                                      unsigned long long* n_undefined_dev);
+void mifc_slab_plan_destroy(mifc_slab_plan* plan);
+int mifc_slab_plan_step(mifc_slab_plan* plan);
+/* 1 when the steps replay a captured graph */
+int mifc_slab_plan_uses_graph(const mifc_slab_plan* plan);
+/* The same step for a caller with a transport of its own (MPI, a host relay, hipMemcpyPeer between the
+ * contexts of one process): begin = counters zeroed + the rows that read no halo row; the caller then fills the
+ * halo rows, ordered on the context's stream; finish = the boundary strips (the whole slab when it is too thin to
+ * split).  Counts stay local: the caller sums them over the slabs. */
+int mifc_slab_plan_begin(mifc_slab_plan* plan);
+int mifc_slab_plan_finish(mifc_slab_plan* plan);
+
 /* Halo transport for a process that drives several GPUs itself (one context per GPU):
  * copies n_floats from src_dev (memory of src_ctx's device) to dst_dev (dst_ctx's device)
  * over xGMI (hipMemcpyPeerAsync), enqueued on dst_ctx's stream and ordered after the work

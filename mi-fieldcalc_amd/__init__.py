@@ -23,7 +23,7 @@ ALL_DEFINED, NONE_DEFINED, SOME_DEFINED = 0, 1, 2  # miutil::ValuesDefined, Fiel
 UNDEF = np.float32(1.0e35)  # miutil::UNDEF, FieldDefined.cc:34
 MEM_HOST, MEM_DEVICE = 0, 1
 
-__all__ = ["Context", "ALL_DEFINED", "NONE_DEFINED", "SOME_DEFINED", "UNDEF", "classify"]
+__all__ = ["Context", "SlabPlan", "ALL_DEFINED", "NONE_DEFINED", "SOME_DEFINED", "UNDEF", "classify"]
 
 
 def classify(n_undefined, n):
@@ -763,6 +763,49 @@ class Context:
         )
         return bool(rc)
 
+    # ---- the decomposed step as one call (include/mifc.h: mifc_comm_*, mifc_slab_plan_*)
+    def comm_unique_id(self):
+        """mifc_comm_unique_id: the bytes rank 0 hands to every rank of a new communicator."""
+        ident = ctypes.create_string_buffer(128)
+        if not self._lib.mifc_comm_unique_id(ctypes.cast(ident, ctypes.c_void_p)):
+            raise RuntimeError("mifc_comm_unique_id failed (RCCL not loadable?)")
+        return ident.raw
+
+    def comm_init(self, ident, rank, world):
+        """mifc_comm_init: a communicator of the library's own for `world` processes, this one being `rank`."""
+        buf = ctypes.create_string_buffer(bytes(ident), 128)
+        if not self._call("mifc_comm_init", [ctypes.cast(buf, ctypes.c_void_p), int(rank), int(world)]):
+            raise RuntimeError("mifc_comm_init: " + self.last_error())
+        return True
+
+    def comm_init_from_torch(self, group=None):
+        """A communicator for the ranks of a torch.distributed group: rank 0's id is broadcast through the group."""
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [self.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return self.comm_init(box[0], rank, world)
+
+    def comm_adopt(self, nccl_comm_ptr):
+        """Use an ncclComm_t the caller owns (an integer address, e.g. ProcessGroupNCCL._comm_ptr())."""
+        return bool(self._call("mifc_comm_adopt", [int(nccl_comm_ptr)]))
+
+    def comm_release(self):
+        return bool(self._lib.mifc_comm_release(self._ctx))
+
+    def comm_info(self):
+        """(has a communicator, rank, world)"""
+        r, w = ctypes.c_int(0), ctypes.c_int(1)
+        has = self._lib.mifc_comm_info(self._ctx, ctypes.cast(ctypes.pointer(r), ctypes.c_void_p), ctypes.cast(ctypes.pointer(w), ctypes.c_void_p))
+        return bool(has), r.value, w.value
+
+    def slab_plan(self, nx, ny_global, j0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, fdefined_in=SOME_DEFINED, undef=UNDEF,
+                  n_undefined=None):
+        """mifc_slab_plan_create on device tensors: u_halo, v_halo (nlev, ny_local + 2, nx) or (ny_local + 2, nx); xmapr, ymapr
+        (ny_local, nx); rvort, diverg (nlev, ny_local, nx) or (ny_local, nx); n_undefined int64[nlev].  -> SlabPlan"""
+        return SlabPlan(self, nx, ny_global, j0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, fdefined_in, undef, n_undefined)
+
     def halo_copy_enqueue(self, dst, src_ctx, src):
         """dst (tensor on this context's device) <- src (tensor on src_ctx's device), see mifc_halo_copy_enqueue."""
         if dst.numel() != src.numel() or not dst.is_contiguous() or not src.is_contiguous():
@@ -779,3 +822,57 @@ class Context:
         self._bind_stream(MEM_DEVICE)
         n = src0.numel()
         return bool(self._call("mifc_bench_stream2", [int(variant), int(blocks), dst0.data_ptr(), dst1.data_ptr(), src0.data_ptr(), src1.data_ptr(), n]))
+
+
+class SlabPlan:
+    """One rank's row slab of a horizontally decomposed level batch, bound to its buffers (mifc_slab_plan_*): step() enqueues
+    the whole decomposed step -- RCCL halo exchange, interior rows meanwhile, boundary strips, count all-reduce -- as one
+    call that replays a HIP graph; begin() / finish() bracket a halo exchange the caller does itself."""
+
+    def __init__(self, ctx, nx, ny_global, j0, ny_local, u_halo, v_halo, xmapr, ymapr, rvort, diverg, fdefined_in, undef, n_undefined):
+        a = [_Arg(x, allow_none=True) for x in (u_halo, v_halo, xmapr, ymapr, rvort, diverg)]
+        nlev = u_halo.shape[0] if u_halo.dim() == 3 else 1
+        halo_shape = (nlev, ny_local + 2, nx) if u_halo.dim() == 3 else (ny_local + 2, nx)
+        out_shape = (nlev, ny_local, nx) if u_halo.dim() == 3 else (ny_local, nx)
+        if not _same_shape(a[:2], halo_shape) or not _same_shape(a[2:4], (ny_local, nx)) or not _same_shape(a[4:], out_shape):
+            raise ValueError("u_halo, v_halo must be ([nlev,] ny_local + 2, nx); xmapr, ymapr (ny_local, nx); rvort, diverg ([nlev,] ny_local, nx)")
+        if _memkind(a, ctx.device) != MEM_DEVICE:
+            raise ValueError("a slab plan takes device tensors only")
+        if n_undefined is not None and n_undefined.numel() < nlev:
+            raise ValueError("n_undefined needs one int64 per level")
+        self._ctx, self._keep = ctx, (u_halo, v_halo, xmapr, ymapr, rvort, diverg, n_undefined)
+        ctx._bind_stream(MEM_DEVICE)
+        self._plan = ctx._lib.mifc_slab_plan_create(ctx._ctx, int(nx), int(ny_global), int(j0), int(ny_local), int(nlev), *[x.addr for x in a],
+                                                    int(fdefined_in), float(undef), None if n_undefined is None else n_undefined.data_ptr())
+        if not self._plan:
+            raise RuntimeError("mifc_slab_plan_create: " + (ctx.last_error() or "invalid arguments"))
+
+    def _run(self, name):
+        self._ctx._bind_stream(MEM_DEVICE)
+        if not getattr(self._ctx._lib, name)(self._plan):
+            raise RuntimeError("%s: %s" % (name, self._ctx.last_error()))
+        return True
+
+    def step(self):
+        return self._run("mifc_slab_plan_step")
+
+    def begin(self):
+        return self._run("mifc_slab_plan_begin")
+
+    def finish(self):
+        return self._run("mifc_slab_plan_finish")
+
+    @property
+    def uses_graph(self):
+        return bool(self._ctx._lib.mifc_slab_plan_uses_graph(self._plan))
+
+    def close(self):
+        if self._plan:
+            self._ctx._lib.mifc_slab_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

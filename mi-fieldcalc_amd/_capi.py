@@ -149,6 +149,18 @@ SIGNATURES = {
     "mifc_vortdiv_slab_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu"]),
     "mifc_vortdiv_slab_rows_enqueue": ("i", ["ctx", "i", "i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu", "i"]),
     "mifc_halo_copy_enqueue": ("i", ["ctx", "p", "ctx", "p", "z"]),
+    # the decomposed step as one call (RCCL from C++, HIP-graph replay)
+    "mifc_comm_unique_id": ("i", ["p"]),
+    "mifc_comm_init": ("i", ["ctx", "p", "i", "i"]),
+    "mifc_comm_adopt": ("i", ["ctx", "p"]),
+    "mifc_comm_release": ("i", ["ctx"]),
+    "mifc_comm_info": ("i", ["ctx", "pi", "pi"]),
+    "mifc_slab_plan_create": ("p", ["ctx", "i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu"]),
+    "mifc_slab_plan_destroy": (None, ["p"]),
+    "mifc_slab_plan_step": ("i", ["p"]),
+    "mifc_slab_plan_uses_graph": ("i", ["p"]),
+    "mifc_slab_plan_begin": ("i", ["p"]),
+    "mifc_slab_plan_finish": ("i", ["p"]),
     # diagnostics
     "mifc_bench_stream2": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "z"]),
     "mifc_diag_division": ("i", ["ctx", "p", "p", "p", "p", "p", "z"]),

@@ -473,6 +473,7 @@ void mifc_destroy(mifc_ctx* c)
     return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  (void)mifc_comm_release(c); // a communicator the library created goes with the context
   for (int s = 0; s < mifc_ctx::NSLOT; ++s)
     if (c->slot[s])
       (void)hipFree(c->slot[s]);

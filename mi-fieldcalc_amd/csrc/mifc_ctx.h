@@ -43,6 +43,11 @@ struct mifc_ctx
   // can be rewritten there (the *_enqueue entry points never synchronise)
   hipEvent_t scratch_read = nullptr;
   bool scratch_read_pending = false;
+  // RCCL communicator of the row-slab path (mifc_comm_init / mifc_comm_adopt; mifc_slab.hip): ncclComm_t, its size and
+  // this process' rank in it; owned = created by the library (destroyed with the context)
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  bool comm_owned = false;
   // chunked, full-duplex streaming of host-resident level batches (created on first use)
   mifc::HostPipe* pipe = nullptr;
   // host fields the caller declared constant (mifc_hold_field): device copies that stage_in reuses

@@ -592,6 +592,120 @@ def test_config4_driver_two_ranks_on_this_gpu(oracle, tmp_path):
     assert _bits_equal(np.load(tmp_path / "config4_diverg.npy"), e)
 
 
+def test_config4_driver_two_ranks_three_levels(tmp_path):
+    """... and a slab that is a batch of three levels (one exchange of three rows per neighbour and field)."""
+    p = _torchrun(2, ["--config", "4", "--size", "1000", "--levels", "3", "--steps", "2", "--warmup", "1", "--check"], {"MIFC_BENCH_BACKEND": "gloo"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    res = _last_json(p.stdout)
+    assert res["verified"] is True and res["n_gpus"] == 2 and "begin / host relay / finish" in res["config"]["step"]
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_config4_driver_one_rank_over_rccl(tmp_path, graph):
+    """One rank, backend nccl: mifc_slab_plan_step (HIP-graph replay, or the direct sequence under MIFC_SLAB_GRAPH=0) on the
+    whole field as ONE slab, checked against the whole-field call; the roofline block is there."""
+    p = _torchrun(1, ["--config", "4", "--size", "1000", "--levels", "2", "--steps", "4", "--warmup", "1", "--check"], {"MIFC_SLAB_GRAPH": graph})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    res = _last_json(p.stdout)
+    assert res["verified"] is True and res["n_gpus"] == 1
+    assert res["config"]["step"] == ("mifc_slab_plan_step, HIP graph replay" if graph == "1" else "mifc_slab_plan_step, direct")
+    assert 0.0 < res["roofline"]["frac"] <= 1.0 and res["roofline"]["per_rank_frac_min"] <= res["roofline"]["per_rank_frac_max"]
+
+
+@pytest.mark.parametrize("nx,ny,nslab,nlev", [(1000, 403, 4, 1), (1440, 360, 3, 5), (516, 64, 8, 2)])
+@pytest.mark.parametrize("mode", ["all", "some"])
+def test_slab_plans_in_loopback_equal_the_whole_field(gpu_ctx, oracle, nx, ny, nslab, nlev, mode):
+    """mifc_slab_plan_begin / finish on every slab of a field held on ONE GPU, the halo rows copied between the slabs in
+    between (what RCCL does between ranks): the assembled levels equal the oracle's whole-field relvort / divergence bit
+    for bit, the summed counts give its flags.  Slabs of unequal height, level batches deep enough for the level-walking
+    kernels, thin slabs that are not split."""
+    import torch
+
+    import mi_fieldcalc_amd as mi_fc
+    import mi_fieldcalc_amd.synth as synth
+    from mi_fieldcalc_amd.sharding import slab_rows
+
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 515 + nx, nlev=nlev)
+    flag = ALL if mode == "all" else SOME
+    if mode == "some":
+        for l in range(nlev):
+            u[l] = synth.sprinkle_undef(u[l], 60 + l, 0.01)
+        v[0, ny // nslab - 1] = cases.UNDEF  # undefined values in a row next to a slab boundary
+    slabs = []
+    for r in range(nslab):
+        j0, n = slab_rows(ny, nslab, r)
+        uh = torch.zeros((nlev, n + 2, nx), device="cuda")
+        vh = torch.zeros_like(uh)
+        uh[:, 1:-1] = torch.from_numpy(u[:, j0:j0 + n]).cuda()
+        vh[:, 1:-1] = torch.from_numpy(v[:, j0:j0 + n]).cuda()
+        rv, dg = torch.empty((nlev, n, nx), device="cuda"), torch.empty((nlev, n, nx), device="cuda")
+        cnt = torch.full((nlev,), 777, dtype=torch.int64, device="cuda")
+        plan = gpu_ctx.slab_plan(nx, ny, j0, n, uh, vh, torch.from_numpy(np.ascontiguousarray(xm[j0:j0 + n])).cuda(),
+                                 torch.from_numpy(np.ascontiguousarray(ym[j0:j0 + n])).cuda(), rv, dg, fdefined_in=flag,
+                                 n_undefined=cnt if flag != ALL else None)
+        slabs.append((j0, n, uh, vh, rv, dg, cnt, plan))
+    for s in slabs:
+        s[7].begin()
+    for r in range(nslab):  # the exchange: my first / last owned rows into the neighbours' halo rows
+        _, n, uh, vh = slabs[r][:4]
+        if r > 0:
+            slabs[r - 1][2][:, -1], slabs[r - 1][3][:, -1] = uh[:, 1], vh[:, 1]
+        if r < nslab - 1:
+            slabs[r + 1][2][:, 0], slabs[r + 1][3][:, 0] = uh[:, n], vh[:, n]
+    for s in slabs:
+        s[7].finish()
+    torch.cuda.synchronize()
+    got_rv = np.concatenate([s[4].cpu().numpy() for s in slabs], axis=1)
+    got_dg = np.concatenate([s[5].cpu().numpy() for s in slabs], axis=1)
+    counts = sum(s[6].cpu().numpy() for s in slabs)
+    for l in range(nlev):
+        ok, e, f = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=flag)
+        assert ok and _bits_equal(got_rv[l], e), l
+        ok, e, f2 = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=flag)
+        assert ok and _bits_equal(got_dg[l], e), l
+        got = ALL if flag == ALL else mi_fc.classify(int(counts[l]), nx * ny - 2 * nx)
+        assert got == f == f2, (l, got, f)
+    for s in slabs:
+        s[7].close()
+
+
+def test_slab_plan_one_rank_communicator_and_graph_replay(gpu_ctx, oracle):
+    """mifc_comm_unique_id / mifc_comm_init for ONE rank (RCCL loaded lazily, ncclCommInitRank) and mifc_slab_plan_step on the
+    whole field as one slab: the second and third step replay the captured graph on NEW input (the graph reads the plan's
+    buffers, not a snapshot)."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 516, 120, 4
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    with fc.Context(0) as ctx:
+        ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+        assert ctx.comm_info() == (True, 0, 1)
+        uh = torch.zeros((nlev, ny + 2, nx), device="cuda")
+        vh = torch.zeros_like(uh)
+        rv, dg = torch.empty((nlev, ny, nx), device="cuda"), torch.empty((nlev, ny, nx), device="cuda")
+        cnt = torch.zeros(nlev, dtype=torch.int64, device="cuda")
+        plan = ctx.slab_plan(nx, ny, 0, ny, uh, vh, torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda(), rv, dg, fdefined_in=SOME, n_undefined=cnt)
+        for it in range(3):
+            u, v = synth.wind(nx, ny, 90 + it, nlev=nlev)
+            u[it] = synth.sprinkle_undef(u[it], it, 0.02)
+            uh[:, 1:-1], vh[:, 1:-1] = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+            plan.step()
+            torch.cuda.synchronize()
+            assert plan.uses_graph
+            c = cnt.cpu().numpy()
+            for l in range(nlev):
+                ok, e, f = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=SOME)
+                assert _bits_equal(rv[l].cpu().numpy(), e) and fc.classify(int(c[l]), nx * ny - 2 * nx) == f, (it, l)
+                ok, e, f = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=SOME)
+                assert _bits_equal(dg[l].cpu().numpy(), e), (it, l)
+        plan.close()
+        assert ctx.comm_release() and ctx.comm_info()[0] is False
+
+
 def test_config5_driver_two_ranks_on_this_gpu():
     p = _torchrun(2, ["--config", "5", "--members", "3", "--nlev", "16", "--steps", "1", "--warmup", "1", "--check"], {"MIFC_BENCH_BACKEND": "gloo"})
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]

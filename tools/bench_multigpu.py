@@ -95,93 +95,138 @@ def config4(args):
 
     import mi_fieldcalc_amd as fc
     import mi_fieldcalc_amd.synth as synth
-    from mi_fieldcalc_amd.sharding import global_undefined_count, slab_rows, vortdiv_slab_overlapped
+    from mi_fieldcalc_amd.sharding import begin_halo_exchange, global_undefined_count, slab_rows, vortdiv_slab_overlapped
 
     world, rank, dev_index, dev, backend = setup()
     nx = ny = args.size
+    nlev = args.levels
     j0, nloc = slab_rows(ny, world, rank)
     # the whole field is generated on every rank from the seed (closed-form waves + seeded noise) and cut:
     # what a rank keeps resident is its slab (+ halo rows, filled by the exchange)
     xm, ym, _ = synth.grid_maps(nx, ny, h=2500.0)
-    u, v = synth.wind(nx, ny, 0x5EED0000 + 4000)
     tested = not args.all_defined
-    if tested:
-        u = synth.sprinkle_undef(u, 41, 0.001)
     flag = fc.SOME_DEFINED if tested else fc.ALL_DEFINED
+    fields = []
+    for l in range(nlev):
+        u, v = synth.wind(nx, ny, 0x5EED0000 + 4000 + l)
+        if tested:
+            u = synth.sprinkle_undef(u, 41 + l, 0.001)
+        fields.append((u, v))
 
-    def slab_with_halo(a):
-        t = torch.zeros((nloc + 2, nx), dtype=torch.float32, device=dev)
-        t[1:-1] = torch.from_numpy(a[j0:j0 + nloc]).to(dev)
+    def slab_with_halo(k):
+        t = torch.zeros((nlev, nloc + 2, nx), dtype=torch.float32, device=dev)
+        for l in range(nlev):
+            t[l, 1:-1] = torch.from_numpy(fields[l][k][j0:j0 + nloc]).to(dev)
         return t
 
-    uh, vh = slab_with_halo(u), slab_with_halo(v)
+    uh, vh = slab_with_halo(0), slab_with_halo(1)
     dxm, dym = torch.from_numpy(np.ascontiguousarray(xm[j0:j0 + nloc])).to(dev), torch.from_numpy(np.ascontiguousarray(ym[j0:j0 + nloc])).to(dev)
-    rv = torch.empty((nloc, nx), dtype=torch.float32, device=dev)
+    rv = torch.empty((nlev, nloc, nx), dtype=torch.float32, device=dev)
     dg = torch.empty_like(rv)
-    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(nlev, dtype=torch.int64, device=dev)
     ctx = fc.Context(dev_index)
     ctx.use_torch_stream()
 
-    def step():
-        if not vortdiv_slab_overlapped(ctx, nx, ny, j0, nloc, uh, vh, dxm, dym, rv, dg, rank, world, fdefined_in=flag, n_undefined=cnt if tested else None):
-            raise RuntimeError(ctx.last_error())
-        if tested:
-            if backend == "nccl":
-                global_undefined_count(cnt)  # 8-byte all-reduce on the device (the next step zeroes the counter again)
-            else:
-                c = cnt.cpu()
-                global_undefined_count(c)
+    # The step is ONE call of the C ABI (mifc_slab_plan_step: RCCL exchange from C++, interior rows meanwhile, strips,
+    # count all-reduce; a HIP graph replayed per step).  --legacy-step keeps round 2's Python-orchestrated sequence
+    # (single level only) for A/B; the gloo rehearsal brackets a host relay of the rows with begin() / finish().
+    plan = None
+    if args.legacy_step:
+        if nlev != 1:
+            raise SystemExit("--legacy-step is the single-level sequence of round 2")
 
-    wall = max_over_ranks(timed_steps(step, args.steps, args.warmup), dev, backend)
+        def step():
+            if not vortdiv_slab_overlapped(ctx, nx, ny, j0, nloc, uh[0], vh[0], dxm, dym, rv[0], dg[0], rank, world, fdefined_in=flag,
+                                           n_undefined=cnt if tested else None):
+                raise RuntimeError(ctx.last_error())
+            if tested:
+                if backend == "nccl":
+                    global_undefined_count(cnt)
+                else:
+                    c = cnt.cpu()
+                    global_undefined_count(c)
+                    cnt.copy_(c)
+    else:
+        plan = ctx.slab_plan(nx, ny, j0, nloc, uh, vh, dxm, dym, rv, dg, fdefined_in=flag, n_undefined=cnt if tested else None)
+        if backend == "nccl":
+            if world > 1:
+                ctx.comm_init_from_torch()
+            step = plan.step
+        else:
+            def step():
+                plan.begin()
+                begin_halo_exchange([uh[l] for l in range(nlev)] + [vh[l] for l in range(nlev)], rank, world).wait()
+                plan.finish()
+                if tested:
+                    c = cnt.cpu()
+                    global_undefined_count(c)
+                    cnt.copy_(c)
+
+    my_wall = timed_steps(step, args.steps, args.warmup)
+    wall = max_over_ranks(my_wall, dev, backend)
+    # this rank's share of the algorithmic traffic per step: 16 B per owned cell and level + its rows of the map factors once
+    my_bytes = nlev * nloc * nx * 16 + 2 * nloc * nx * 4
+    my_frac = my_bytes / (my_wall / args.steps) / 8e12
+    fr = torch.tensor([my_frac, -my_frac], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(fr, op=dist.ReduceOp.MAX)
+    frac_max, frac_min = float(fr[0]), -float(fr[1])
 
     out = {
-        "metric": "Mcells/s fused vorticity+divergence, one %dx%d field in %d row slabs (BASELINE.json configs[3])" % (nx, ny, world),
-        "value": round(nx * ny * args.steps / wall / 1e6, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": "Mcells/s fused vorticity+divergence, %d level(s) of one %dx%d field in %d row slabs (BASELINE.json configs[3])" % (nlev, nx, ny, world),
+        "value": round(nlev * nx * ny * args.steps / wall / 1e6, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "dtype": "f32 in/out, f64 combine",
         "data": "synthetic",
-        "config": {"workload": "%dx%d float32 single level, row slabs of %d..%d rows, 1-row halo of u and v per neighbour exchanged each step "
+        "roofline": {"bound": "hbm", "achieved": round((nlev * nx * ny * 16 + 2 * nx * ny * 4) / (wall / args.steps) / 1e9, 1), "peak": 8000.0 * world,
+                     "unit": "GB/s", "frac": round((nlev * nx * ny * 16 + 2 * nx * ny * 4) / (wall / args.steps) / 8e12 / world, 4),
+                     "per_rank_frac_min": round(frac_min, 4), "per_rank_frac_max": round(frac_max, 4), "traffic": None,
+                     "note": "whole step on the wall clock (exchange, launches and reduce included), not kernel time"},
+        "config": {"workload": "%d level(s) of %dx%d float32, row slabs of %d..%d rows, 1-row halo of u and v per level and neighbour exchanged each step "
                                "(RCCL send/recv, overlapped with the interior rows), %s" % (
-                                   nx, ny, ny // world, -(-ny // world), "per-cell undefined tests + 8-byte count all-reduce" if tested else "ALL_DEFINED inputs"),
+                                   nlev, nx, ny, ny // world, -(-ny // world), "per-cell undefined tests + count all-reduce" if tested else "ALL_DEFINED inputs"),
+                   "step": "round-2 Python sequence" if args.legacy_step else ("mifc_slab_plan_step, HIP graph replay" if plan.uses_graph else
+                                                                               ("mifc_slab_plan_step, direct" if backend == "nccl" else "mifc_slab_plan_begin / host relay / finish")),
                    "backend": backend},
     }
     if args.check:
         # one more decomposed pass, then every slab against rank 0's whole-field result, bit for bit
-        cnt.zero_()
-        assert vortdiv_slab_overlapped(ctx, nx, ny, j0, nloc, uh, vh, dxm, dym, rv, dg, rank, world, fdefined_in=flag, n_undefined=cnt if tested else None)
+        step()
         torch.cuda.synchronize()
-        total = cnt.clone() if backend == "nccl" else cnt.cpu()
-        global_undefined_count(total)
+        total = cnt.clone()  # every form of the step leaves the whole field's counts on every rank
         ok = True
         whole = None
         if rank == 0:
-            du, dv_ = torch.from_numpy(u).to(dev)[None], torch.from_numpy(v).to(dev)[None]
+            du = torch.from_numpy(np.stack([f[0] for f in fields])).to(dev)
+            dv_ = torch.from_numpy(np.stack([f[1] for f in fields])).to(dev)
             fx, fy = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
-            (wrv, wdg), wflag = ctx.vortdiv_levels(du, dv_, fx, fy, fdefined=[flag])
-            whole = (wrv[0], wdg[0], int(wflag[0]))
+            (wrv, wdg), wflag = ctx.vortdiv_levels(du, dv_, fx, fy, fdefined=[flag] * nlev)
+            whole = (wrv, wdg, [int(f) for f in wflag])
             ctx.use_torch_stream()
         # gather the slabs on rank 0 (through the host: this is the checker, not the timed path)
         parts = [None] * world if rank == 0 else None
         dist.gather_object((j0, nloc, rv.cpu().numpy(), dg.cpu().numpy()), parts, dst=0)
         if rank == 0:
-            got_rv = np.empty((ny, nx), np.float32)
-            got_dg = np.empty((ny, nx), np.float32)
+            got_rv = np.empty((nlev, ny, nx), np.float32)
+            got_dg = np.empty((nlev, ny, nx), np.float32)
             for pj0, pn, prv, pdg in parts:
-                got_rv[pj0:pj0 + pn], got_dg[pj0:pj0 + pn] = prv, pdg
+                got_rv[:, pj0:pj0 + pn], got_dg[:, pj0:pj0 + pn] = prv, pdg
             wrv_h, wdg_h = whole[0].cpu().numpy(), whole[1].cpu().numpy()
             same = lambda a, b: bool(np.array_equal(a.view(np.uint32)[~np.isnan(a)], b.view(np.uint32)[~np.isnan(b)]) and np.array_equal(np.isnan(a), np.isnan(b)))
-            got_flag = fc.ALL_DEFINED if not tested else fc.classify(int(total.item()), nx * ny - 2 * nx)
-            ok = same(got_rv, wrv_h) and same(got_dg, wdg_h) and got_flag == whole[2]
+            counts = [int(x) for x in total.cpu().numpy()]
+            got_flags = [fc.ALL_DEFINED if not tested else fc.classify(c, nx * ny - 2 * nx) for c in counts]
+            ok = same(got_rv, wrv_h) and same(got_dg, wdg_h) and got_flags == whole[2]
             out["verified"] = ok
-            out["check"] = "every slab == rank 0's whole-field result bit for bit; global undefined count %d -> flag %d" % (int(total.item()), got_flag)
+            out["check"] = "every slab == rank 0's whole-field result bit for bit; global undefined counts %s -> flags %s" % (counts[:4], got_flags[:4])
             if args.dump:
                 os.makedirs(args.dump, exist_ok=True)
-                np.save(os.path.join(args.dump, "config4_rvort.npy"), got_rv)
-                np.save(os.path.join(args.dump, "config4_diverg.npy"), got_dg)
+                np.save(os.path.join(args.dump, "config4_rvort.npy"), got_rv[0])
+                np.save(os.path.join(args.dump, "config4_diverg.npy"), got_dg[0])
                 with open(os.path.join(args.dump, "config4_meta.json"), "w") as f:
-                    json.dump({"nx": nx, "ny": ny, "seed": 0x5EED0000 + 4000, "tested": tested, "flag": got_flag, "count": int(total.item())}, f)
+                    json.dump({"nx": nx, "ny": ny, "seed": 0x5EED0000 + 4000, "tested": tested, "flag": got_flags[0], "count": counts[0]}, f)
         ok = all_true(ok, dev, backend)
         if rank == 0 and not ok:
             out["verified"] = False
+    if plan is not None:
+        plan.close()
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
@@ -277,6 +322,8 @@ def main():
     ap.add_argument("--dump", default=None, help="config 4 + --check: directory for the assembled result (rank 0)")
     ap.add_argument("--size", type=int, default=4000, help="config 4: the field is size x size")
     ap.add_argument("--all-defined", action="store_true", help="config 4: ALL_DEFINED inputs (no tests, no count all-reduce)")
+    ap.add_argument("--levels", type=int, default=1, help="config 4: levels in the slab batch (one exchange of that many rows per neighbour and field)")
+    ap.add_argument("--legacy-step", action="store_true", help="config 4: round 2's Python-orchestrated step (A/B)")
     ap.add_argument("--members", type=int, default=51, help="config 5")
     ap.add_argument("--nlev", type=int, default=137, help="config 5")
     args = ap.parse_args()
