@@ -205,7 +205,7 @@ def pmc_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20 on one GPU, 100 on several: the max over ranks of a 7.7 ms region is thin)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison with the CPU reference path before timing (profiling runs)")
@@ -217,8 +217,11 @@ def main():
                          "combination of arrays a kernel streams decides its time by up to 12 %%); 0 = four allocations as they come")
     ap.add_argument("--placement-rounds", type=int, default=3, help="pools searched one after the other (each of --placement-pool arrays, --placement-tries probes); the best set is kept")
     ap.add_argument("--placement-tries", type=int, default=240, help="probes (index sets of the pool timed with the kernel) the search may spend; the fastest set is kept")
+    ap.add_argument("--no-as-allocated", action="store_true", help="do not time the same launch on four plain allocations (roofline_as_allocated)")
     ap.add_argument("--level-stride", type=int, default=None, help="floats between levels (default: the library's mifc_batch_level_stride)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.gpus <= 1 else 100
 
     import numpy as np
     import torch
@@ -287,12 +290,24 @@ def main():
     # "allocated in one go" -- would have given) goes into the JSON line.  --placement-pool 0: four allocations as they come.
     warmed = []
     from mi_fieldcalc_amd.placement import choose_search_rounds
-    if args.placement_pool >= 4:
-        # ... and a pool of 48 can still hold none (two of five processes of one round-end run): up to three pools, the best set kept
-        (du, dv, rv, dg), placement = choose_search_rounds(lambda: ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride), 4, probe_batch,
-                                                           rounds=args.placement_rounds, pool_size=args.placement_pool, random_sets=48,
-                                                           max_probes=max(1, args.placement_tries), device=dev)
-    else:
+    # the pools are sized to what is free on THIS device (ranks may share one in rehearsals; other tenants): at most a third
+    # of the free memory per pool round, and four plain allocations when even a small pool does not fit or runs out of memory
+    pool = args.placement_pool
+    if pool >= 4:
+        free_b, _ = torch.cuda.mem_get_info(dev)
+        per_array = level_stride * NLEV * 4
+        pool = min(pool, int(free_b * 0.9 / max(1, args.placement_rounds) / per_array))
+    placement = None
+    if pool >= 8:
+        try:
+            # ... and a pool of 48 can still hold none (two of five processes of one round-end run): up to three pools, the best set kept
+            (du, dv, rv, dg), placement = choose_search_rounds(lambda: ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride), 4, probe_batch,
+                                                               rounds=args.placement_rounds, pool_size=pool, random_sets=48,
+                                                               max_probes=max(1, args.placement_tries), device=dev)
+        except torch.cuda.OutOfMemoryError:
+            torch.cuda.empty_cache()
+            placement = None
+    if placement is None:
         du, dv, rv, dg = (ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride) for _ in range(4))
         placement = {"method": "four allocations as they come"}
     du.copy_(su)
@@ -325,8 +340,8 @@ def main():
             step(check)
         ev1.record()
         torch.cuda.synchronize()
+        wall = time.perf_counter() - t0  # this rank's K steps; the closing barrier (an RCCL kernel of ~0.1 ms) is not part of them
         barrier()
-        wall = time.perf_counter() - t0
         return wall, ev0.elapsed_time(ev1) / nsteps
 
     def per_launch(nsteps, check=False):
@@ -376,10 +391,36 @@ def main():
     torch.cuda.synchronize()
     wall, kernel_avg_ms = timed(args.steps)
     kern_ms = per_launch(max(10, args.steps))
+    # the same four-array batch "as allocated": four plain allocations made now, timed like the headline (what a caller who
+    # allocates a batch and computes gets; 65-72 % of peak depending on the process)
+    as_allocated = None
+    if not args.no_as_allocated and world == 1:
+        try:
+            keep = (du, dv, rv, dg)
+            du, dv, rv, dg = (ctx.batch_empty(NLEV, NY, NX, level_stride=level_stride) for _ in range(4))
+            du.copy_(keep[0])
+            dv.copy_(keep[1])
+            for _ in range(max(3, args.warmup)):
+                step()
+            torch.cuda.synchronize()
+            _, aa_ms = timed(args.steps)
+            as_allocated = {"kernel_ms_avg": round(aa_ms, 4), "frac": round(algorithmic_bytes(NX, NY, NLEV) / (aa_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "four plain allocations, no placement search; same launch, same K steps between one pair of events"}
+            du, dv, rv, dg = keep
+            del keep
+            torch.cuda.empty_cache()
+        except torch.cuda.OutOfMemoryError:
+            du, dv, rv, dg = keep
+            torch.cuda.empty_cache()
+    per_rank_frac = None
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
+        mine = algorithmic_bytes(NX, NY, NLEV) / (kernel_avg_ms / 1e3) / 1e9 / HBM_PEAK_GBS
+        f = torch.tensor([mine, -mine], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        per_rank_frac = {"min": round(-float(f[1]), 4), "max": round(float(f[0]), 4)}
 
     cells_per_step = NX * NY * NLEV
     value = cells_per_step * world * args.steps / wall / 1e6
@@ -419,7 +460,9 @@ def main():
             "kernel_ms_avg": round(avg_kernel_s * 1e3, 4),
             "kernel_ms_avg_note": "one pair of HIP events around the K launches of the timed region, / K",
             "per_launch_event_pairs_ms": {"median": round(float(np.median(kern_ms)), 4), "min": round(float(np.min(kern_ms)), 4), "max": round(float(np.max(kern_ms)), 4)},
+            "per_rank_frac": per_rank_frac,
         },
+        "roofline_as_allocated": as_allocated,
     }
     if rank == 0 and world == 1 and not args.no_check_variant:
         du[:, 100:110, 200:260] = float(fc.UNDEF)  # some undefined cells so that the count path does real work

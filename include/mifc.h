@@ -84,6 +84,32 @@ void* mifc_device_alloc(mifc_ctx* ctx, size_t bytes);
 int mifc_device_free(mifc_ctx* ctx, void* dptr);
 int mifc_copy_to_device(mifc_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int mifc_copy_to_host(mifc_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* Device memory for a batch that is allocated once and computed on many times, PLACED: which physical memory the
+ * arrays a streaming kernel touches lie on decides its time by up to 12 %, stably for as long as they live (DESIGN.md
+ * 4.1).  n_arrays arrays of bytes_each bytes; their addresses come back in arrays_out[n_arrays].
+ *   MIFC_PLACE_AS_ALLOCATED  n_arrays plain allocations, as they come
+ *   MIFC_PLACE_SEARCH        a pool of up to 48 arrays (never more than budget_bytes, 0 = no budget of the caller's, and
+ *                            never more than 90 % of the free device memory) is allocated, index sets of it are timed with
+ *                            the probe -- structured and random sets, then coordinate descent, at most 160 probes -- the
+ *                            fastest set is kept and the rest freed (what mi-fieldcalc_amd/placement.py does for bench.py)
+ *   MIFC_PLACE_VMM           opt-in: ONE physical allocation made and mapped by the library (hipMemCreate / hipMemMap),
+ *                            the arrays a measured-good distance apart inside it; no search
+ *                            (profiles/r03/experiments/vmm_placement_*.txt, and the caveat in mifc_placement.hip)
+ * probe(user, arrays) -> milliseconds of a representative kernel over the candidate arrays, in arrays_out order (a negative
+ * value aborts the call); NULL = the library times its own fused vorticity+divergence launch over the first four arrays
+ * as (u, v, rvort, diverg) of a nx x ny x nlev batch, which must fit bytes_each.  report may be NULL.
+ * Free with mifc_batch_free_placed (all arrays of one call together). */
+enum { MIFC_PLACE_AS_ALLOCATED = 0, MIFC_PLACE_SEARCH = 1, MIFC_PLACE_VMM = 2 };
+typedef float (*mifc_placement_probe_fn)(void* user, void* const* arrays);
+typedef struct mifc_placement_report {
+  int strategy, pool_size, probes;
+  float as_allocated_ms; /* the first n_arrays arrays of the pool: what allocating the batch in one go gives */
+  float chosen_ms, probe_ms_min, probe_ms_median, probe_ms_max;
+  size_t array_distance_bytes; /* MIFC_PLACE_VMM: distance between the arrays inside the one allocation */
+} mifc_placement_report;
+int mifc_batch_alloc_placed(mifc_ctx* ctx, int n_arrays, size_t bytes_each, int strategy, size_t budget_bytes, int nx, int ny, int nlev,
+                            mifc_placement_probe_fn probe, void* probe_user, void** arrays_out, mifc_placement_report* report);
+int mifc_batch_free_placed(mifc_ctx* ctx, void** arrays, int n_arrays);
 /* Host-pointer (MIFC_MEM_HOST) callers: declare a host array that is passed to
  * many calls unchanged -- xmapr, ymapr, fcoriolis of a grid (FieldCalculations.h:
  * every stencil operator takes them) -- so that it is uploaded once instead of

@@ -43,6 +43,8 @@ SIGNATURES = {
     "mifc_device_free": ("i", ["ctx", "p"]),
     "mifc_copy_to_device": ("i", ["ctx", "p", "p", "z"]),
     "mifc_copy_to_host": ("i", ["ctx", "p", "p", "z"]),
+    "mifc_batch_alloc_placed": ("i", ["ctx", "i", "z", "i", "z", "i", "i", "i", "p", "p", "p", "p"]),
+    "mifc_batch_free_placed": ("i", ["ctx", "p", "i"]),
     "mifc_hold_field": ("i", ["ctx", "p", "z"]),
     "mifc_release_field": ("i", ["ctx", "p"]),
     "mifc_timing_begin": ("i", ["ctx"]),

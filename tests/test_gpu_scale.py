@@ -556,6 +556,85 @@ def test_wrapper_rejects_mismatched_fields(gpu_ctx):
         gpu_ctx.stencil_levels("gradient3", lev, None, maps[:10], maps)
 
 
+# ------------------------------------------------------------------ placed batches through the C ABI
+class _PlacementReport(__import__("ctypes").Structure):
+    import ctypes as _c
+
+    _fields_ = [("strategy", _c.c_int), ("pool_size", _c.c_int), ("probes", _c.c_int), ("as_allocated_ms", _c.c_float), ("chosen_ms", _c.c_float),
+                ("probe_ms_min", _c.c_float), ("probe_ms_median", _c.c_float), ("probe_ms_max", _c.c_float), ("array_distance_bytes", _c.c_size_t)]
+
+
+def _placed_batch_roundtrip(gpu_ctx, oracle, strategy, probe=None, budget=0):
+    """mifc_batch_alloc_placed -> the four arrays of a small level batch; fused vorticity+divergence on them through raw
+    device pointers == the oracle; mifc_batch_free_placed."""
+    import ctypes
+
+    import mi_fieldcalc_amd.synth as synth
+
+    lib, ctx = gpu_ctx._lib, gpu_ctx._ctx
+    nx, ny, nlev = 1440, 60, 6
+    n = nx * ny * nlev
+    arrays = (ctypes.c_void_p * 4)()
+    rep = _PlacementReport()
+    cb = ctypes.cast(probe, ctypes.c_void_p) if probe is not None else None
+    ok = lib.mifc_batch_alloc_placed(ctx, 4, n * 4, strategy, budget, nx, ny, nlev, cb, None, ctypes.cast(arrays, ctypes.c_void_p),
+                                     ctypes.cast(ctypes.pointer(rep), ctypes.c_void_p))
+    assert ok, gpu_ctx.last_error()
+    assert len({int(a) for a in arrays}) == 4 and all(int(a) % 256 == 0 for a in arrays)
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 4711, nlev=nlev)
+    dxm, dym = lib.mifc_device_alloc(ctx, nx * ny * 4), lib.mifc_device_alloc(ctx, nx * ny * 4)
+    for dst, src in ((arrays[0], u), (arrays[1], v), (dxm, xm), (dym, ym)):
+        assert lib.mifc_copy_to_device(ctx, dst, src.ctypes.data, src.nbytes)
+    flags = np.full(nlev, ALL, np.int32)
+    assert lib.mifc_vortdiv_levels(ctx, nx, ny, nlev, arrays[0], arrays[1], dxm, dym, arrays[2], arrays[3], flags.ctypes.data, 1e35, 1), gpu_ctx.last_error()
+    rv, dg = np.empty_like(u), np.empty_like(u)
+    assert lib.mifc_copy_to_host(ctx, rv.ctypes.data, arrays[2], rv.nbytes) and lib.mifc_copy_to_host(ctx, dg.ctypes.data, arrays[3], dg.nbytes)
+    for l in (0, nlev - 1):
+        ok, e, _ = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=ALL)
+        assert ok and _bits_equal(rv[l], e)
+        ok, e, _ = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=ALL)
+        assert ok and _bits_equal(dg[l], e)
+    assert lib.mifc_batch_free_placed(ctx, ctypes.cast(arrays, ctypes.c_void_p), 4) and all(a is None for a in arrays)
+    lib.mifc_device_free(ctx, dxm)
+    lib.mifc_device_free(ctx, dym)
+    return rep
+
+
+def test_batch_alloc_placed_search_with_the_librarys_probe(gpu_ctx, oracle):
+    rep = _placed_batch_roundtrip(gpu_ctx, oracle, 1)
+    assert rep.strategy == 1 and rep.pool_size == 48 and 4 < rep.probes <= 160
+    assert 0.0 < rep.probe_ms_min <= rep.chosen_ms <= rep.as_allocated_ms <= rep.probe_ms_max and rep.chosen_ms == rep.probe_ms_min
+    # a budget of ten arrays: a pool of ten
+    rep = _placed_batch_roundtrip(gpu_ctx, oracle, 1, budget=10 * 1440 * 60 * 6 * 4)
+    assert rep.pool_size == 10 and rep.probes > 1
+    rep = _placed_batch_roundtrip(gpu_ctx, oracle, 0)
+    assert rep.strategy == 0 and rep.pool_size == 4 and rep.probes == 0
+
+
+def test_batch_alloc_placed_search_with_a_callers_probe(gpu_ctx, oracle):
+    """The search keeps the set the probe likes best: a synthetic probe that prefers arrays at low addresses ends up with the
+    four lowest of the pool in ascending order of cost."""
+    import ctypes
+
+    seen = []
+
+    @ctypes.CFUNCTYPE(ctypes.c_float, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p))
+    def probe(user, arrays):
+        a = [int(arrays[k]) for k in range(4)]
+        seen.append(tuple(a))
+        return 1.0 + 1e-12 * sum((k + 1) * x for k, x in enumerate(a)) % 1.0
+
+    rep = _placed_batch_roundtrip(gpu_ctx, oracle, 1, probe=probe)
+    assert rep.probes == len(set(seen)) and rep.chosen_ms == rep.probe_ms_min
+
+
+@pytest.mark.skipif(os.environ.get("MIFC_TEST_VMM") != "1", reason="opt-in: MIFC_PLACE_VMM maps memory with HIP's virtual-memory API (MIFC_TEST_VMM=1)")
+def test_batch_alloc_placed_virtual_memory_strategy(gpu_ctx, oracle):
+    rep = _placed_batch_roundtrip(gpu_ctx, oracle, 2)
+    assert rep.strategy == 2 and 96 <= (rep.array_distance_bytes >> 20) % 256 <= 128 and rep.chosen_ms > 0
+
+
 # ------------------------------------------------------------------ N-rank drivers
 def _torchrun(nproc, script_args, env_extra, timeout=600):
     env = dict(os.environ, **env_extra)
