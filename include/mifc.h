@@ -327,6 +327,18 @@ int mifc_vortdiv_levels_strided_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev,
                                         const float* ymapr, float* rvort, float* diverg, size_t in_level_stride, size_t out_level_stride,
                                         const int* fdefined_in, float undef, unsigned long long* n_undefined_dev);
 
+/* Vorticity, divergence AND the wind speed ff = vectorabs(u, v) (FieldCalculations.cc:1819) of a level batch in one
+ * pass: what BASELINE.json config 5 computes per ensemble member from u and v.  As two calls ff reads u and v a second
+ * time (12 B per cell); here it is a third output of the fused kernel, computed from the rows that are in LDS anyway
+ * (20 B per cell for the three results instead of 16 + 12).  ff : [nlev][ny][nx], every cell (rows 0 and ny-1 included);
+ * n_undefined_ff_dev : device u64[nlev], classify against nx*ny (:1839); n_undefined_dev as in
+ * mifc_vortdiv_levels_enqueue.  The input flag of a level governs all three results, as it would in the three reference
+ * calls.  Per level each result is bit-identical to its reference function.  Launches the three-output kernel does not
+ * take (shallow or small batches, nx % 4 != 0, ...) run the pair and a batched vectorabs: same results, two launches. */
+int mifc_vortdiv_ff_levels_enqueue(mifc_ctx* ctx, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr,
+                                   const float* ymapr, float* rvort, float* diverg, float* ff, const int* fdefined_in, float undef,
+                                   unsigned long long* n_undefined_dev, unsigned long long* n_undefined_ff_dev);
+
 /* Any stencil operator over a batch of levels (generic form of the call above).
  * op selects the reference function:
  *   MIFC_OP_RELVORT .cc:1843, _ABSVORT :1875, _DIVERGENCE :1910, _VORTDIV (both),

@@ -604,6 +604,25 @@ class Context:
         )
         return bool(rc)
 
+    def vortdiv_ff_levels_enqueue(self, u, v, xmapr, ymapr, rvort, diverg, ff, fdefined=None, undef=UNDEF, n_undefined=None, n_undefined_ff=None):
+        """Vorticity, divergence and the wind speed of a level batch in one pass (mifc_vortdiv_ff_levels_enqueue); device tensors
+        (nlev, ny, nx); n_undefined / n_undefined_ff: int64[nlev] (classify against nx*ny - 2*nx / nx*ny), None allowed when every
+        level is ALL_DEFINED."""
+        a = [_Arg(x) for x in (u, v, xmapr, ymapr, rvort, diverg, ff)]
+        if len(a[0].shape) != 3:
+            raise ValueError("u, v must have shape (nlev, ny, nx)")
+        nlev, ny, nx = a[0].shape
+        if not _same_shape([a[1], a[4], a[5], a[6]], a[0].shape) or not _same_shape(a[2:4], (ny, nx)):
+            raise ValueError("u, v, rvort, diverg, ff must be (nlev, ny, nx) and xmapr, ymapr (ny, nx)")
+        if _memkind(a, self.device) != MEM_DEVICE:
+            raise ValueError("the *_enqueue calls take device tensors only")
+        flags = None if fdefined is None else np.array(fdefined, dtype=np.int32).reshape(nlev).copy()
+        self._bind_stream(MEM_DEVICE)
+        rc = self._call("mifc_vortdiv_ff_levels_enqueue", [nx, ny, nlev] + [x.addr for x in a] + [
+            None if flags is None else flags.ctypes.data, float(undef), None if n_undefined is None else n_undefined.data_ptr(),
+            None if n_undefined_ff is None else n_undefined_ff.data_ptr()])
+        return bool(rc)
+
     def stencil_levels_enqueue(self, op, f0, f1, xmapr, ymapr, fcoriolis, out0, out1=None, fdefined=None, undef=UNDEF, n_undefined=None):
         """Asynchronous form of stencil_levels on device tensors (mifc_stencil_levels_enqueue): nothing is read back;
         n_undefined: int64 CUDA tensor[nlev] (None allowed when every level is ALL_DEFINED).  The flag of level l is

@@ -125,6 +125,7 @@ SIGNATURES = {
     # batched
     "mifc_vortdiv_levels": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
     "mifc_stencil_levels": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "i"]),
+    "mifc_vortdiv_ff_levels_enqueue": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "pu", "pu"]),
     "mifc_stencil_levels_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "pu"]),
     "mifc_stencil_count_domain": ("u64", ["i", "i", "i"]),
     "mifc_stencil_levels_ex": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "f", "i", "p", "p", "pi", "f", "i"]),

@@ -1524,6 +1524,116 @@ int mifc_vortdiv_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const flo
   return mifc_vortdiv_levels_strided_enqueue(c, nx, ny, nlev, u, v, xmapr, ymapr, rvort, diverg, n, n, fdefined_in, undef, n_undefined_dev);
 }
 
+int mifc_vortdiv_ff_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const float* u, const float* v, const float* xmapr, const float* ymapr,
+                                   float* rvort, float* diverg, float* ff, const int* fdefined_in, float undef, unsigned long long* n_undefined_dev,
+                                   unsigned long long* n_undefined_ff_dev)
+{
+  if (!c || !rvort || !diverg || !ff || !u || !v || !xmapr || !ymapr)
+    return 0;
+  enter(c);
+  if (nx < 3 || ny < 3 || nlev < 1)
+    return 0;
+  if (!ensure_levels(c, (size_t)nlev))
+    return 0;
+  bool every_all = (fdefined_in != nullptr);
+  std::vector<unsigned char> hf((size_t)nlev);
+  for (int l = 0; l < nlev; ++l) {
+    hf[l] = (fdefined_in && fdefined_in[l] == MIFC_ALL_DEFINED) ? 1 : 0;
+    every_all = every_all && hf[l];
+  }
+  if (!every_all && (!n_undefined_dev || !n_undefined_ff_dev)) {
+    c->err = "mifc_vortdiv_ff_levels_enqueue: both counter arrays are required unless every level is ALL_DEFINED";
+    return 0;
+  }
+  const bool piecewise = nlev > mifc::kPrepMaxLevels;
+  if (!every_all) {
+    if (piecewise) {
+      if (!pinned_acquire(c))
+        return 0;
+      std::memcpy(pinned_flags(c), hf.data(), (size_t)nlev);
+      MIFC_HIP(c, hipMemcpyAsync(c->d_flags, pinned_flags(c), (size_t)nlev, hipMemcpyHostToDevice, c->stream));
+      if (!pinned_release(c))
+        return 0;
+      MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64) * (size_t)nlev, c->stream));
+      MIFC_HIP(c, hipMemsetAsync(n_undefined_ff_dev, 0, sizeof(u64) * (size_t)nlev, c->stream));
+    } else {
+      MIFC_HIP(c, mifc::launch_prep_levels(hf.data(), nlev, c->d_flags, n_undefined_dev, nlev, c->stream));
+      MIFC_HIP(c, mifc::launch_prep_levels(nullptr, nlev, nullptr, n_undefined_ff_dev, nlev, c->stream));
+    }
+  }
+  mifc::StencilParams P;
+  std::memset(&P, 0, sizeof P);
+  P.op = mifc::ST_VORTDIV;
+  P.nx = nx;
+  P.ny_global = ny;
+  P.ny_local = ny;
+  P.nlev = nlev;
+  P.f0 = u;
+  P.f1 = v;
+  P.xmapr = xmapr;
+  P.ymapr = ymapr;
+  P.out0 = rvort;
+  P.out1 = diverg;
+  P.out_ff = ff;
+  P.n_undefined_ff = n_undefined_ff_dev;
+  P.in_level_stride = (long)nx * ny;
+  P.out_level_stride = (long)nx * ny;
+  P.undef = undef;
+  P.every_level_all_defined = every_all ? 1 : 0;
+  P.all_defined = c->d_flags;
+  P.n_undefined = n_undefined_dev;
+  const bool timed = c->timing && c->n_timed < mifc_ctx::NTIMED;
+  if (timed)
+    (void)hipEventRecord(c->tev[2 * c->n_timed], c->stream);
+  hipError_t e = mifc::launch_stencil(P, c->stream);
+  if (e == hipErrorNotSupported) {
+    // not a launch the three-output kernel takes (shallow or small batch, ragged width, NaN undef, a forced tuning): the
+    // pair as usual and the wind speed as a launch of its own (the batched vectorabs of mifc_derived.hip)
+    (void)hipGetLastError();
+    P.out_ff = nullptr;
+    P.n_undefined_ff = nullptr;
+    e = mifc::launch_stencil(P, c->stream);
+    if (e == hipSuccess && (nx * ny) % 4 != 0) {
+      // a cell count the batched vectorabs does not take: level by level on the single-field kernel
+      for (int l = 0; l < nlev && e == hipSuccess; ++l) {
+        const int fl = hf[l] ? MIFC_ALL_DEFINED : MIFC_SOME_DEFINED;
+        mifc::EwiseParams E = ewise_base(mifc::EW_VECTORABS, nx, ny, &fl, undef);
+        E.in0 = u + (size_t)l * nx * ny;
+        E.in1 = v + (size_t)l * nx * ny;
+        E.out = ff + (size_t)l * nx * ny;
+        E.count = hf[l] ? 0 : 1;
+        E.n_undefined = hf[l] ? nullptr : n_undefined_ff_dev + l;
+        e = mifc::launch_ewise(E, c->stream);
+      }
+    } else if (e == hipSuccess) {
+      mifc::DerivedParams D;
+      std::memset(&D, 0, sizeof D);
+      D.n = nx * ny;
+      D.nlev = nlev;
+      D.u = u;
+      D.v = v;
+      D.ff = ff;
+      D.wind_all_defined = c->d_flags;
+      D.thermo_all_defined = c->d_flags;
+      D.every_level_all_defined = every_all ? 1 : 0;
+      D.undef = undef;
+      D.cnt_ff = n_undefined_ff_dev;
+      e = mifc::launch_derived_levels(D, c->stream);
+    }
+  }
+  if (timed) {
+    (void)hipEventRecord(c->tev[2 * c->n_timed + 1], c->stream);
+    c->n_timed += 1;
+  }
+  if (e != hipSuccess) {
+    fail(c, "mifc_vortdiv_ff_levels_enqueue: launch", e);
+    return 0;
+  }
+  if (!every_all && !scratch_release(c)) // the kernels read c->d_flags
+    return 0;
+  return 1;
+}
+
 unsigned long long mifc_stencil_count_domain(int op, int nx, int ny)
 {
   return stencil_denominator(op, nx, ny);

@@ -238,6 +238,11 @@ struct StencilParams
   const float* fcoriolis;
   float* out0;
   float* out1;   // second output (ST_VORTDIV diverg, ST_IGWIND vg); may be null
+  // ST_VORTDIV over whole fields only, optional: the wind speed sqrt(u*u + v*v) of every cell as a third output and its
+  // per-level undefined counts (vectorabs :1819, count domain nx*ny).  launch_vortdiv_rows leaves *handled false when the
+  // launch is not one the split-role kernel takes; launch_stencil then returns hipErrorNotSupported
+  float* out_ff;
+  u64* n_undefined_ff;
   long in_level_stride;  // elements between consecutive levels of f0/f1
   long out_level_stride; // same for out0/out1
   const unsigned char* all_defined; // device u8[nlev] or null

@@ -628,6 +628,8 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
     const hipError_t e = launch_vortdiv_rows(prm, stream, &handled);
     if (handled)
       return e;
+    if (prm.out_ff)
+      return hipErrorNotSupported; // the caller computes the wind speed as a launch of its own
   }
   if (prm.op >= ST_GRAD_X && prm.op <= ST_IGWIND) {
     bool handled = false;

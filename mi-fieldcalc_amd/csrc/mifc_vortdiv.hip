@@ -83,6 +83,8 @@ struct RowsParams
   const float *u, *v, *xm, *ym;
   const float* fc; // coriolis parameter, absvort only
   float *rv, *dv;
+  float* ff;          // split-role kernel only: wind speed sqrt(u*u + v*v) of every cell as a third output (vectorabs, :1819), or null
+  u64* n_undefined_ff; // its per-level undefined counts (count domain nx*ny, :1839)
   long in_stride, out_stride;
   const unsigned char* all_defined;
   float undef;
@@ -1065,10 +1067,16 @@ chunk_done:;
 // WANT_V / WANT_D: which of the two results the launch produces (relvort or divergence alone read the very same rows:
 // 12 instead of 16 B per cell); ABSV: the vorticity gets the tile's Coriolis parameter added (absvort, :1896), which
 // lives in registers next to the map factors for the whole walk.
-template <bool CHECK, bool NT, int TR, int NL, int PF, bool WANT_V = true, bool WANT_D = true, bool ABSV = false>
+// FF: a third output, the wind speed ff = sqrt(u*u + v*v) of every cell (vectorabs, FieldCalculations.cc:1819-1841: float
+// arithmetic, its own test on exactly (u[i], v[i]), its own count over ALL nx*ny cells) from the rows of u and v that are in
+// LDS anyway -- BASELINE.json config 5 computes ff next to vorticity and divergence per member, and as a separate launch ff
+// reads u and v a second time (44 -> 36 B per cell for the member).  Rows 0 and ny-1 have no compute wave of their own: the
+// waves of rows 1 and ny-2, which fill them for the stencil outputs, compute their ff from the halo slots.
+template <bool CHECK, bool NT, int TR, int NL, int PF, bool WANT_V = true, bool WANT_D = true, bool ABSV = false, bool FF = false>
 __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const RowsParams P)
 {
   static_assert(WANT_V || WANT_D, "nothing to compute");
+  static_assert(!FF || (WANT_V && WANT_D && !ABSV), "the wind speed rides on the fused pair");
   static_assert(!ABSV || (WANT_V && !WANT_D), "absvort is a single-output operator");
   constexpr int NB = PF + 1;                // level buffers
   constexpr int NS = TR + 2;                // row slots per level: slot s holds tile row s - 1
@@ -1081,8 +1089,11 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
   // global counter after the barrier of level l + 1 -- ONE global atomic per workgroup and level (same-address atomics are
   // served one after the other: a masked field made the per-wave atomics cost twice the kernel)
   __shared__ unsigned int sbad[2];
-  if (CHECK && threadIdx.x < 2)
+  __shared__ unsigned int sbadf[2]; // the same for the wind speed's counts
+  if (CHECK && threadIdx.x < 2) {
     sbad[threadIdx.x] = 0; // ordered before the first use by the barrier of the first level
+    sbadf[threadIdx.x] = 0;
+  }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int bid = blockIdx.x;
@@ -1165,6 +1176,13 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
           if (n != 0) {
             atomicAdd(P.n_undefined + lev_done, (u64)n);
             sbad[q] = 0; // the next adds into this slot come after the next barrier
+          }
+          if constexpr (FF) {
+            const unsigned int nf = sbadf[q];
+            if (nf != 0) {
+              atomicAdd(P.n_undefined_ff + lev_done, (u64)nf);
+              sbadf[q] = 0;
+            }
           }
         }
       };
@@ -1309,6 +1327,43 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
         const unsigned int n = wave_sum(bad);
         if (lane == 0)
           atomicAdd(&sbad[(lev - lev0) & 1], n);
+      }
+      if constexpr (FF) {
+        // vectorabs (:1831-1837) of this wave's row -- and of row 0 / ny-1 in the waves next to them -- in float, tested on
+        // the cell's own u and v
+        unsigned int badf = 0;
+        float* ffp = P.ff + (size_t)lev * P.out_stride;
+        auto speed_row = [&](const v4f& ur, const v4f& vr, int at) {
+          float f[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            bool okf = true;
+            if (CHECK)
+              okf = all | ((bool)__builtin_islessgreater(ur[k], undef) & (bool)__builtin_islessgreater(vr[k], undef));
+            const float a = absval(ur[k], vr[k]);
+            f[k] = okf ? a : undef;
+            if (CHECK)
+              badf += (!okf & act) ? 1u : 0u;
+          }
+          if (act) {
+            v4f f4;
+            f4.x = f[0];
+            f4.y = f[1];
+            f4.z = f[2];
+            f4.w = f[3];
+            store4<NT>(ffp + at, f4);
+          }
+        };
+        speed_row(uc, vc, oo);
+        if (top)
+          speed_row(srow[buf][slot - 1][0][lane], srow[buf][slot - 1][1][lane], oo - nx);
+        if (bottom)
+          speed_row(srow[buf][slot + 1][0][lane], srow[buf][slot + 1][1][lane], oo + nx);
+        if (CHECK && P.n_undefined_ff && !all && __builtin_amdgcn_ballot_w64(badf != 0) != 0) {
+          const unsigned int n = wave_sum(badf);
+          if (lane == 0)
+            atomicAdd(&sbadf[(lev - lev0) & 1], n);
+        }
       }
     }
     buf = (buf + 1 == NB) ? 0 : buf + 1;
@@ -1511,6 +1566,11 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   // the split-role kernel's tests are ONE compare per value ("ordered and != undef"), which is is_def() only for an
   // undef that is not NaN: a NaN undef takes the kernels with the generic two-compare test
   const bool nan_undef_tested = !prm.every_level_all_defined && prm.undef != prm.undef;
+  // the wind speed as a third output exists in the split-role form only (whole fields, fused pair): anything else is left to
+  // the caller, which runs vectorabs as a launch of its own
+  if (prm.out_ff && !(rv && dv && prm.op == ST_VORTDIV && prm.j0 == 0 && prm.ny_local == prm.ny_global && prm.row_end <= prm.row_begin && !nan_undef_tested &&
+                      env().split_roles && env().levelwalk && !env().has_vortdiv_tune && prm.nlev >= kLevelWalkMinLevels))
+    return hipSuccess;
   Tuning t = current_tuning(nx);
   while (t.WPB > 1 && t.WPB / 2 >= prm.nlev)
     t.WPB /= 2; // fewer levels than waves: do not launch waves that only stage map factors
@@ -1613,6 +1673,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.fc = (prm.op == ST_ABSVORT) ? prm.fcoriolis : nullptr;
   rp.rv = rv;
   rp.dv = dv;
+  rp.ff = prm.out_ff;
+  rp.n_undefined_ff = prm.n_undefined_ff;
   rp.in_stride = prm.in_level_stride;
   rp.out_stride = prm.out_level_stride;
   rp.all_defined = prm.all_defined;
@@ -1620,6 +1682,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.n_undefined = prm.n_undefined;
   int grid = rp.per_xcd * 8;
 
+  if (prm.out_ff && t.K != 4)
+    return hipSuccess; // (see above: only the split-role kernel has the third output)
   *handled = true;
   if ((t.K == 1 || t.K == 2) && rp.fc) { // one-shot forms of absvort (relvort + the Coriolis parameter)
     const bool tiles = t.K == 2;
@@ -1801,6 +1865,10 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     hipLaunchKernelGGL((vortdiv_split_kernel<true, true, TR_, NL_, PF_, ##__VA_ARGS__>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp); \
   else                                                                                                                                     \
     hipLaunchKernelGGL((vortdiv_split_kernel<false, true, TR_, NL_, PF_, ##__VA_ARGS__>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp)
+    if (prm.out_ff) { // the fused pair plus the wind speed: the default shape
+      SPLIT_AS(12, 2, 2, true, true, false, true);
+      return hipGetLastError();
+    }
     if (single) {
       const bool pf1 = pf == 1;
       if (rp.fc) {

@@ -712,6 +712,37 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc
             assert fo[l] == f_e, (name, l, fo[l], f_e)
 
 
+@pytest.mark.parametrize("nx,ny,nlev,walk", [(516, 70, 6, "1"), (1440, 40, 9, "1"), (260, 11, 5, "1"), (64, 48, 2, None), (949, 23, 4, "1"), (1440, 75, 5, None)])
+def test_vortdiv_ff_levels_three_outputs_in_one_pass(gpu_ctx, oracle, nx, ny, nlev, walk, mifc_env):
+    """mifc_vortdiv_ff_levels_enqueue: relvort, divergence and vectorabs of every level == the three reference calls bit for
+    bit, flags from the two counter arrays (count domains nx*ny - 2*nx and nx*ny).  walk="1" forces the split-role
+    three-output kernel whatever the launch size (rows 0 / ny-1 of ff come from the halo slots there); the other shapes
+    (two levels, a ragged width, a launch below the threshold) take the pair + batched vectorabs route."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+
+    mifc_env("MIFC_LEVELWALK_MIN_UNITS", walk)
+    u, v, xm, ym, flags = _levels_inputs(nx, ny, nlev, 5150 + nx)
+    v[0, 0, 3] = cases.UNDEF  # an undefined value in row 0: counts for ff, not for the stencil outputs of that column's interior
+    u[nlev - 1, ny - 1, nx - 1] = np.nan
+    rv_e, dv_e, fo_e = _expect_levels(oracle, u, v, xm, ym, flags)
+    du, dvv, dxm, dym = (torch.from_numpy(a).cuda() for a in (u, v, xm, ym))
+    rv, dg, ff = torch.empty_like(du), torch.empty_like(du), torch.empty_like(du)
+    cnt = torch.full((nlev,), 99, dtype=torch.int64, device="cuda")
+    cnt_ff = torch.full((nlev,), 99, dtype=torch.int64, device="cuda")
+    assert gpu_ctx.vortdiv_ff_levels_enqueue(du, dvv, dxm, dym, rv, dg, ff, fdefined=flags, n_undefined=cnt, n_undefined_ff=cnt_ff)
+    torch.cuda.synchronize()
+    assert cases.same_bits(rv.cpu().numpy(), rv_e, nan_payload=False) and cases.same_bits(dg.cpu().numpy(), dv_e, nan_payload=False)
+    c, cf = cnt.cpu().numpy(), cnt_ff.cpu().numpy()
+    ffh = ff.cpu().numpy()
+    for l in range(nlev):
+        ok, e, f_e = oracle.call("vectorabs", nx, ny, u[l], v[l], fdefined=int(flags[l]))
+        assert ok and cases.same_bits(ffh[l], e, nan_payload=False), l
+        assert (ALL if flags[l] == ALL else fc.classify(int(cf[l]), nx * ny)) == f_e, (l, cf[l], f_e)
+        assert (ALL if flags[l] == ALL else fc.classify(int(c[l]), nx * ny - 2 * nx)) == fo_e[l], (l, c[l], fo_e[l])
+
+
 def test_stencil_levels_enqueue_equals_the_synchronous_call(gpu_ctx, oracle):
     """mifc_stencil_levels_enqueue (nothing read back; counts stay on the device) against mifc_stencil_levels: same fields bit
     for bit, and classify(count, mifc_stencil_count_domain) gives the flags -- plevelgwind_xcomp excepted, which is

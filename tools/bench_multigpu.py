@@ -265,9 +265,14 @@ def config5(args):
 
     def member_pass(k):
         s = sets[k % nsets]
-        ok = ctx.hlevel_derived_levels_enqueue(s["u"], s["v"], s["t"], s["q"], s["ps"], al, bl, s["ff"], s["rh"], s["th"], s["cnt"],
-                                               fdef_wind=flags, fdef_thermo=flags)
-        ok = ok and ctx.vortdiv_levels_enqueue(s["u"], s["v"], dxm, dym, s["rv"], s["dg"], fdefined=flags)
+        if args.unfused_ff:  # round 2: ff in the derived launch (reads u, v), the stencil pair in a second one (reads u, v again): 44 B/cell
+            ok = ctx.hlevel_derived_levels_enqueue(s["u"], s["v"], s["t"], s["q"], s["ps"], al, bl, s["ff"], s["rh"], s["th"], s["cnt"],
+                                                   fdef_wind=flags, fdef_thermo=flags)
+            ok = ok and ctx.vortdiv_levels_enqueue(s["u"], s["v"], dxm, dym, s["rv"], s["dg"], fdefined=flags)
+        else:  # ff rides on the fused vorticity + divergence kernel (u, v read once: 36 B/cell); RH and theta from t, q, ps
+            ok = ctx.hlevel_derived_levels_enqueue(s["u"], s["v"], s["t"], s["q"], s["ps"], al, bl, None, s["rh"], s["th"], s["cnt"],
+                                                   fdef_wind=flags, fdef_thermo=flags)
+            ok = ok and ctx.vortdiv_ff_levels_enqueue(s["u"], s["v"], dxm, dym, s["rv"], s["dg"], s["ff"], fdefined=flags)
         if not ok:
             raise RuntimeError(ctx.last_error())
 
@@ -282,29 +287,53 @@ def config5(args):
         "value": round(cells * args.steps / wall / 1e6, 1), "unit": "Mcells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "dtype": "f32 (f64 combine / x^kappa)",
         "data": "synthetic",
-        "config": {"workload": "%d members sharded over %d ranks (%d on the busiest), per member 2 launches over %d levels: fused ff+RH+theta (28 B/cell) and "
-                               "fused relvort+divergence (16 B/cell); inputs ALL_DEFINED, resident in HBM, two rotating member-sized buffer sets per rank" % (
-                                   nmem, world, -(-nmem // world), nlev),
-                   "algorithmic_bytes_per_member": nx * ny * nlev * 44 + 3 * nx * ny * 4, "backend": backend},
+        "config": {"workload": ("%d members sharded over %d ranks (%d on the busiest), per member 2 launches over %d levels: " % (nmem, world, -(-nmem // world), nlev))
+                   + ("fused ff+RH+theta (28 B/cell) and fused relvort+divergence (16 B/cell)" if args.unfused_ff else
+                      "fused RH+theta (16 B/cell) and fused relvort+divergence+ff (20 B/cell: u and v are read once per member)")
+                   + "; inputs ALL_DEFINED, resident in HBM, two rotating member-sized buffer sets per rank",
+                   "algorithmic_bytes_per_member": nx * ny * nlev * (44 if args.unfused_ff else 36) + 3 * nx * ny * 4, "backend": backend},
     }
+    bytes_member = out["config"]["algorithmic_bytes_per_member"]
+    out["roofline"] = {"bound": "hbm", "achieved": round(bytes_member * nmem * args.steps / wall / 1e9, 1), "peak": 8000.0 * world, "unit": "GB/s",
+                       "frac": round(bytes_member * nmem * args.steps / wall / 8e12 / world, 4), "traffic": None,
+                       "note": "whole pipeline on the wall clock, max over ranks"}
     if args.check:
-        # sampled levels of this rank's first member: batched kernels == single-field entry points
+        # sampled levels of this rank's first member against the CPU reference path (oracle/_ref when built, else the
+        # restatement) -- the checker, outside every timed region: the stencil outputs and ff bit for bit, RH and theta
+        # within 1e-5 relative (BASELINE.json; a libm power per cell)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import cpulib
+
+        which = "ref" if cpulib.available("ref") else "oracle"
+        cpu = cpulib.CpuLib(which)
         s = sets[0]
         member_pass(0)
         torch.cuda.synchronize()
         ok = True
-        same = lambda a, b: bool(torch.equal(a.view(torch.int32), b.view(torch.int32)))
+        h = lambda x: x.cpu().numpy()  # noqa: E731
+        bits = lambda a, b: bool(np.array_equal(a.view(np.uint32), b.view(np.uint32)))  # noqa: E731
+        close = lambda a, b: bool(np.all(np.abs(a.astype(np.float64) - b) <= 1e-5 * np.abs(b.astype(np.float64)) + 1e-30))  # noqa: E731
+        ps_h = h(s["ps"])
+        worst = 0.0
         for l in sorted({0, nlev // 2, nlev - 1}):
-            r1, _ = ctx.relvort(s["u"][l], s["v"][l], dxm, dym, fdefined=fc.ALL_DEFINED)
-            d1, _ = ctx.divergence(s["u"][l], s["v"][l], dxm, dym, fdefined=fc.ALL_DEFINED)
-            f1, _ = ctx.vectorabs(s["u"][l], s["v"][l], fdefined=fc.ALL_DEFINED)
-            h1, _ = ctx.hlevelhum(s["t"][l], s["q"][l], s["ps"], float(al[l]), float(bl[l]), "", 1, fdefined=fc.ALL_DEFINED)
-            t1, _ = ctx.hleveltemp(s["t"][l], s["ps"], float(al[l]), float(bl[l]), "", 3, fdefined=fc.ALL_DEFINED)
-            ok = ok and same(r1, s["rv"][l]) and same(d1, s["dg"][l]) and same(f1, s["ff"][l]) and same(h1, s["rh"][l]) and same(t1, s["th"][l])
+            ul, vl, tl, ql = h(s["u"][l]), h(s["v"][l]), h(s["t"][l]), h(s["q"][l])
+            _, e, _ = cpu.call("relvort", nx, ny, ul, vl, xm, ym, fdefined=fc.ALL_DEFINED)
+            ok = ok and bits(h(s["rv"][l]), e)
+            _, e, _ = cpu.call("divergence", nx, ny, ul, vl, xm, ym, fdefined=fc.ALL_DEFINED)
+            ok = ok and bits(h(s["dg"][l]), e)
+            _, e, _ = cpu.call("vectorabs", nx, ny, ul, vl, fdefined=fc.ALL_DEFINED)
+            ok = ok and bits(h(s["ff"][l]), e)
+            _, e, _ = cpu.call("hlevelhum", nx, ny, tl, ql, ps_h, float(al[l]), float(bl[l]), "", 1, fdefined=fc.ALL_DEFINED)
+            ok = ok and close(h(s["rh"][l]), e)
+            worst = max(worst, float(np.max(np.abs(h(s["rh"][l]).astype(np.float64) - e) / np.maximum(np.abs(e), 1e-30))))
+            _, e, _ = cpu.call("hleveltemp", nx, ny, tl, ps_h, float(al[l]), float(bl[l]), "", 3, fdefined=fc.ALL_DEFINED)
+            ok = ok and close(h(s["th"][l]), e)
+            worst = max(worst, float(np.max(np.abs(h(s["th"][l]).astype(np.float64) - e) / np.maximum(np.abs(e), 1e-30))))
         ctx.use_torch_stream()
         ok = all_true(ok, dev, backend)
         out["verified"] = ok
-        out["check"] = "levels 0 / mid / last of every rank's first member: batched kernels == single-field kernels bit for bit"
+        out["check"] = ("levels 0 / mid / last of every rank's first member against the %s CPU path: relvort, divergence, ff bit for bit; RH, theta within "
+                        "1e-5 relative (rank 0 worst %.2e)" % ("reference" if which == "ref" else "restated", worst))
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
@@ -324,6 +353,7 @@ def main():
     ap.add_argument("--all-defined", action="store_true", help="config 4: ALL_DEFINED inputs (no tests, no count all-reduce)")
     ap.add_argument("--levels", type=int, default=1, help="config 4: levels in the slab batch (one exchange of that many rows per neighbour and field)")
     ap.add_argument("--legacy-step", action="store_true", help="config 4: round 2's Python-orchestrated step (A/B)")
+    ap.add_argument("--unfused-ff", action="store_true", help="config 5: round 2's pipeline, ff in the derived launch (A/B: 44 instead of 36 B/cell)")
     ap.add_argument("--members", type=int, default=51, help="config 5")
     ap.add_argument("--nlev", type=int, default=137, help="config 5")
     args = ap.parse_args()
