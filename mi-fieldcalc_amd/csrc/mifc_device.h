@@ -530,16 +530,19 @@ __device__ __forceinline__ float f_diverg(float xm, float ym, float dudx, float 
 // FieldCalculations.cc:1951-1952 only mentions it in a comment): the meteorological wind direction,
 // i.e. where the wind blows FROM, in degrees clockwise from north:
 //   dd = 270 - atan2(v, u) * 180 / pi, brought into [0, 360); calm (u == v == 0) gives 0.
-// Evaluated in float (atan2f); the definition, not a reference result, is what tests pin.
+// Evaluated in float as dd = atan2(-u, -v) * 180 / pi (+360 when negative): the same angle as 270 - atan2(v, u) * 180 / pi
+// without the subtraction, whose cancellation near north (dd -> 0) cost all relative accuracy (round 2: 2e-3 degrees
+// absolute).  Now within 1e-5 RELATIVE of the float64 definition rounded once (oracle/mifc_oracle.cc: mifcorc_winddir)
+// everywhere; the definition, not a reference result, is what the tests pin.
 __device__ __forceinline__ float wind_direction(float u, float v)
 {
   if (u == 0.f && v == 0.f)
     return 0.f;
-  float dd = 270.f - atan2f(v, u) * 57.29577951308232f;
-  if (dd >= 360.f)
-    dd -= 360.f;
+  float dd = atan2f(-u, -v) * 57.29577951308232f;
   if (dd < 0.f)
     dd += 360.f;
+  if (dd >= 360.f || dd == 0.f) // -1e-6 + 360 rounds to 360: the same direction as 0; and no negative zero (wind from due north)
+    dd = 0.f;
   return dd;
 }
 

@@ -55,6 +55,41 @@ int mifcorc_vectorabs(int nx, int ny, const float* u, const float* v, float* ff,
   return 1;
 }
 
+// EXTENSION -- NO REFERENCE FUNCTION: BASELINE.json's north_star names "wind direction from u/v", the
+// reference only mentions one in comments (FieldCalculations.cc:1951-1952, :2190-2191).  The definition the product
+// implements (mifc_winddir, csrc/mifc_device.h wind_direction): the meteorological direction the wind blows FROM, degrees
+// clockwise from north, dd = 270 - atan2(v, u) * 180 / pi brought into [0, 360), calm (u == v == 0) -> 0; undefined
+// handling and flag as vectorabs (:1831-1839).  Restated here in float64 and rounded to float ONCE: the yardstick the
+// device's float evaluation is held to (1e-5 relative).  Parity of this operator is pinned by this definition only; the
+// compiled reference has no counterpart (oracle/ref_shim.cc exports none).
+int mifcorc_winddir(int nx, int ny, const float* u, const float* v, float* dd, int* fdefined, float undef)
+{
+  const int n = nx * ny;
+  const bool all = (*fdefined == ALL_DEFINED);
+  size_t n_undefined = 0;
+  for (int i = 0; i < n; ++i) {
+    if (all || (defined1(u[i], undef) && defined1(v[i], undef))) {
+      double d = 0.0;
+      if (!(u[i] == 0.f && v[i] == 0.f)) {
+        d = 270.0 - std::atan2((double)v[i], (double)u[i]) * (180.0 / 3.14159265358979323846);
+        if (d >= 360.0)
+          d -= 360.0;
+        if (d < 0.0)
+          d += 360.0;
+      }
+      float f = (float)d;
+      if (f >= 360.f) // 359.99999... rounds up to 360: the same direction as 0
+        f = 0.f;
+      dd[i] = f;
+    } else {
+      dd[i] = undef;
+      n_undefined += 1;
+    }
+  }
+  *fdefined = classify(n_undefined, n);
+  return 1;
+}
+
 // FieldCalculations.cc:1843-1873
 int mifcorc_relvort(int nx, int ny, const float* u, const float* v, const float* xmapr, const float* ymapr, float* out, int* fdefined, float undef)
 {

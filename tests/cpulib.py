@@ -101,6 +101,8 @@ SIGS = {
     "extremeValue": "CTno",
     "probability": "CTDnVo",
 }
+# restatement only: the product's EXTENSION "wind direction from u/v" has no reference function
+ORACLE_ONLY = {"winddir": "ppo"}
 _CT = {"p": [_F], "o": [_F], "f": [_R], "s": [_S], "i": [_I], "T": [_F], "D": [_F], "n": [_I], "V": [_F, _I]}
 
 
@@ -116,7 +118,8 @@ class CpuLib:
         self.which = which
         self._lib = ctypes.CDLL(path)
         self._fn = {}
-        for name, sig in SIGS.items():
+        self._sigs = dict(SIGS, **(ORACLE_ONLY if which == "oracle" else {}))
+        for name, sig in self._sigs.items():
             fn = getattr(self._lib, prefix + name)
             fn.restype = _I
             lead = [_I] if sig.startswith("C") else []
@@ -129,7 +132,7 @@ class CpuLib:
     def call(self, name, nx, ny, *args, fdefined=SOME_DEFINED, undef=UNDEF, outs=None):
         """args in reference order (fields as numpy float32 arrays, scalars,
         strings); outputs are allocated here.  Returns (ok, out or (out0,out1), flag)."""
-        sig = SIGS[name]
+        sig = self._sigs[name]
         lead = []
         if sig.startswith("C"):
             lead, args, sig = [int(args[0])], args[1:], sig[1:]

@@ -78,17 +78,24 @@ def celsius_output(case):
     return False
 
 
-def ill_conditioned_cells(case):
-    """Cells where the REFERENCE's own result has no bounded condition number, so that a 1-ulp
-    difference in powf (glibc's vs the device's) may legitimately exceed any relative bound.
+# where the reference's extrapolated e(T) crosses zero: e = ewt[0] + (ewt[1] - ewt[0]) * x with x = (tC + 100) * 0.2 < 0
+# (MetConstants.h:56-80: ewt[0] = .000034, ewt[1] = .000089)
+_EWT0, _EWT1 = np.float64(np.float32(0.000034)), np.float64(np.float32(0.000089))
+TC_ZERO_OF_E = 5.0 * (-_EWT0 / (_EWT1 - _EWT0)) - 100.0  # -103.0909... C
 
-    ewt_calculator (MetConstants.h:64-80) truncates x = (tC + 100) * 0.2 toward zero, so temperatures
-    in (-105, -100) C count as "defined" with l = 0 and a NEGATIVE interpolation weight: the saturation
-    pressure is extrapolated, e = ewt[0] + (ewt[1] - ewt[0]) * x, and crosses zero at tC = -103.09 C.
-    Next to that zero every quantity formed from e (qsat, RH, Td, theta-e, ducting) is a quotient of
-    something by almost nothing.  Only operators that compute the temperature from a potential
-    temperature with a per-cell powf can differ there at all (everything else is bit-exact).
-    Returns a boolean mask (or None): temperature within the extrapolated bin, +-0.01 K."""
+
+def conditioning_slack(case):
+    """Per-cell factor (>= 1) on the 1e-5 bound for the operators that derive the temperature from a potential temperature
+    with a per-cell powf, or None.
+
+    ewt_calculator (MetConstants.h:64-80) truncates x = (tC + 100) * 0.2 toward zero, so temperatures in (-105, -100) C count
+    as "defined" with l = 0 and a NEGATIVE interpolation weight: the saturation pressure is extrapolated and crosses zero at
+    tC = -103.09 C.  Every result formed from e there (qsat, RH, Td, theta-e, ducting) is a quotient by e = slope * (tC - T0):
+    a temperature that differs by dT (one or two float spacings of tk ~ 170 K, 1.5e-5 K each, between glibc's and the
+    device's powf) changes it by the RELATIVE amount dT / |tC - T0|, which exceeds 1e-5 within about 3 K of the crossing
+    whatever the implementation.  Round 2 excluded the whole bin from the value comparison (87 000 cells); now every cell is
+    compared, with the bound 1e-5 * max(1, 4e-5 K / |tC - T0| / 1e-5) -- the propagated effect of a temperature off by
+    4e-5 K (< 3 float spacings), nothing more."""
     op = case.get("op")
     args = case.get("args", [])
     if op in ("hlevelhum", "hlevelducting", "hlevelthe"):
@@ -104,7 +111,9 @@ def ill_conditioned_cells(case):
         return None
     with np.errstate(all="ignore"):
         tc = np.asarray(theta, np.float64) * np.power(p / 1000.0, 287.0 / 1004.0) - 273.15
-        return (tc > -105.01) & (tc < -99.99)
+        in_bin = (tc > -105.01) & (tc < -99.99)
+        slack = np.where(in_bin, np.maximum(1.0, 4.0 / np.maximum(np.abs(tc - TC_ZERO_OF_E), 1e-12)), 1.0)
+    return np.where(np.isfinite(slack), slack, 1.0)
 
 
 # per operator: [cells compared under the 1e-5 bound, cells beyond a STRICT 1e-5 * |expected|, largest strict relative error]
@@ -134,19 +143,27 @@ def compare(case, got, expected, exact):
     assert np.array_equal(gu, eu), "%s: undef placement differs" % case["label"]
     assert np.array_equal(gn, en), "%s: NaN placement differs" % case["label"]
     m = ~(eu | en) & np.isfinite(expected)
-    ill = ill_conditioned_cells(case)
-    if ill is not None and ill.any():
-        ill = ill.reshape(expected.shape)
-        rec = STRICT.setdefault("%s: cells in the extrapolated bin of the e(T) table, excluded" % case.get("op", "?"), [0, 0, 0.0])
-        rec[0] += int(np.count_nonzero(ill & m))
-        m = m & ~ill
+    slack = conditioning_slack(case)
+    if slack is not None:
+        slack = slack.reshape(expected.shape)[m]
+        rec = STRICT.setdefault("%s: cells in the extrapolated bin of the e(T) table, compared under the propagated bound" % case.get("op", "?"), [0, 0, 0.0])
+        rec[0] += int(np.count_nonzero(slack > 1.0))
     err = np.abs(got[m].astype(np.float64) - expected[m].astype(np.float64))
     floor = 273.15 if celsius_output(case) else 0.0
     if case.get("op") == "windCooling":
         floor = 30.0  # 13.12 - 11.37 * ff^0.16 + ...: the bound is relative to the terms that cancel, not to the small difference
     tol = 1e-5 * (np.abs(expected[m].astype(np.float64)) + floor) + 1e-30
+    if slack is not None:
+        tol = tol * slack
     if err.size:
         rel = err / (np.abs(expected[m].astype(np.float64)) + 1e-30)
+        if slack is not None and np.any(slack > 1.0):
+            rec = STRICT["%s: cells in the extrapolated bin of the e(T) table, compared under the propagated bound" % case.get("op", "?")]
+            rec[1] += int(np.count_nonzero(rel[slack > 1.0] > 1e-5))
+            rec[2] = max(rec[2], float(rel[slack > 1.0].max()))
+            rel = rel[slack <= 1.0]
+            if not rel.size:
+                rel = np.zeros(1)
         key = "%s%s" % (case.get("op", "?"), " (vs |x|+%g)" % floor if floor else "")
         rec = STRICT.setdefault(key, [0, 0, 0.0])
         rec[0] += int(err.size)
