@@ -123,6 +123,14 @@ int mifc_release_field(mifc_ctx* ctx, const float* host_field);
  * -1 on error or after more than 16 launches. */
 int mifc_timing_begin(mifc_ctx* ctx);
 float mifc_timing_end_ms(mifc_ctx* ctx);
+/* The asynchronous entry points zero the caller's undefined counters before they count (one small fill per call).
+ * A caller that issues many small calls back to back -- or records them into a graph, where every fill is a node of
+ * ~5 us -- can zero ALL its counters with one mifc_zero_counts_enqueue and switch the per-call fills off:
+ * mifc_counts_accumulate(ctx, 1) makes mifc_stencil_levels_enqueue, mifc_vortdiv_levels*_enqueue and
+ * mifc_hlevel_derived_*_enqueue ADD to the counters they are given (0 switches back; the synchronous entries and the
+ * slab plans are not affected). */
+int mifc_counts_accumulate(mifc_ctx* ctx, int on);
+int mifc_zero_counts_enqueue(mifc_ctx* ctx, unsigned long long* counts_dev, size_t n);
 /* miutil::checkDefined(size_t,size_t), FieldDefined.cc:62-70 */
 int mifc_classify(unsigned long long n_undefined, unsigned long long n);
 
@@ -461,6 +469,29 @@ int mifc_vortdiv_slab_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int 
 int mifc_vortdiv_slab_rows_enqueue(mifc_ctx* ctx, int nx, int ny_global, int j0, int ny_local, int row_begin, int row_end, const float* u_halo,
                                    const float* v_halo, const float* xmapr, const float* ymapr, float* rvort, float* diverg, int fdefined_in,
                                    float undef, unsigned long long* n_undefined_dev, int accumulate_count);
+/* ---- launch-bound work as one launch: HIP-graph capture of a sequence of calls ----------------- */
+/* The reference is called once per 2-D field; a caller that keeps its loop over levels pays a launch per level for
+ * microseconds of traffic (one 1440x720 level of the fused derived kernel: 33 MB = 4 us at peak).  Between
+ * mifc_graph_begin and mifc_graph_end the context's ASYNCHRONOUS entry points (mifc_*_enqueue, mifc_slab_plan_begin /
+ * _finish) do not run: their launches are recorded with the arguments given; mifc_graph_launch replays the recorded
+ * sequence on the context's stream with one runtime call, any number of times (the buffers are read when the graph
+ * runs, not when it was recorded).  The synchronous entry points (everything that returns a flag) cannot be recorded:
+ * the capture is invalidated and mifc_graph_end returns NULL.  max_levels_per_call: the deepest level batch of the
+ * recorded calls (the per-level scratch is sized before the capture starts; 0 = 256).  One capture per context at a
+ * time; mifc_set_stream must not be called in between.
+ * Lanes: calls that do not depend on each other -- the levels of a caller's loop -- may be recorded side by side
+ * (mifc_graph_begin_lanes + mifc_graph_lane(k) before a call): every lane is a chain of its own in the graph, all lanes
+ * start together and the graph ends when all have ended, so the launch gaps of one lane are filled by the others.  The
+ * caller vouches that calls in different lanes touch different outputs.  Calls that need the context's per-level
+ * scratch (stencil batches with mixed flags, derived batches of more than 8 levels) are refused in a multi-lane capture. */
+typedef struct mifc_graph mifc_graph;
+int mifc_graph_begin(mifc_ctx* ctx, int max_levels_per_call);
+int mifc_graph_begin_lanes(mifc_ctx* ctx, int max_levels_per_call, int n_lanes /* 1 .. 16 */);
+int mifc_graph_lane(mifc_ctx* ctx, int lane);
+mifc_graph* mifc_graph_end(mifc_ctx* ctx);
+int mifc_graph_launch(mifc_graph* graph);
+void mifc_graph_destroy(mifc_graph* graph);
+
 /* ---- the decomposed step as ONE call (BASELINE.json config 4) --------------- */
 /* Communicator: RCCL over xGMI, one process per GPU.  Either the library creates it -- rank 0 calls
  * mifc_comm_unique_id(), the caller distributes the MIFC_COMM_ID_BYTES bytes to every rank by any means it

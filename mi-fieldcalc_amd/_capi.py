@@ -50,6 +50,8 @@ SIGNATURES = {
     "mifc_timing_begin": ("i", ["ctx"]),
     "mifc_timing_end_ms": ("fl", ["ctx"]),
     "mifc_classify": ("i", ["u64", "u64"]),
+    "mifc_counts_accumulate": ("i", ["ctx", "i"]),
+    "mifc_zero_counts_enqueue": ("i", ["ctx", "pu", "z"]),
     # elementwise
     "mifc_vectorabs": ("i", ["ctx", "i", "i", "p", "p", "p", "pi", "f", "i"]),
     "mifc_pleveltemp": ("i", ["ctx", "i", "i", "p", "f", "s", "i", "p", "pi", "f", "i"]),
@@ -152,6 +154,13 @@ SIGNATURES = {
     "mifc_vortdiv_slab_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu"]),
     "mifc_vortdiv_slab_rows_enqueue": ("i", ["ctx", "i", "i", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "i", "f", "pu", "i"]),
     "mifc_halo_copy_enqueue": ("i", ["ctx", "p", "ctx", "p", "z"]),
+    # a sequence of *_enqueue calls recorded into a HIP graph
+    "mifc_graph_begin": ("i", ["ctx", "i"]),
+    "mifc_graph_begin_lanes": ("i", ["ctx", "i", "i"]),
+    "mifc_graph_lane": ("i", ["ctx", "i"]),
+    "mifc_graph_end": ("p", ["ctx"]),
+    "mifc_graph_launch": ("i", ["p"]),
+    "mifc_graph_destroy": (None, ["p"]),
     # the decomposed step as one call (RCCL from C++, HIP-graph replay)
     "mifc_comm_unique_id": ("i", ["p"]),
     "mifc_comm_init": ("i", ["ctx", "p", "i", "i"]),

@@ -130,6 +130,13 @@ bool pinned_release(mifc_ctx* c)
 
 bool scratch_release(mifc_ctx* c)
 {
+  if (c->capturing && c->n_lanes > 1) {
+    // the context's per-level scratch (flags, hybrid coefficients) is ONE set: calls recorded side by side would overwrite it
+    // under each other's kernels
+    c->err = "a call that needs the context's per-level scratch was recorded into a capture with several lanes: record level batches of at most 8 "
+             "levels (their flags and coefficients travel in the kernel arguments), or use one lane";
+    return false;
+  }
   hipError_t e = hipEventRecord(c->scratch_read, c->stream);
   if (e != hipSuccess)
     return fail(c, "hipEventRecord", e);
@@ -499,6 +506,8 @@ void mifc_destroy(mifc_ctx* c)
   mifc::hostpipe_destroy(c->pipe);
   for (const mifc_ctx::HeldField& h : c->held)
     (void)hipFree(h.dev);
+  if (c->capture_stream)
+    (void)hipStreamDestroy(c->capture_stream);
   if (c->own_stream)
     (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -527,6 +536,10 @@ int mifc_set_stream(mifc_ctx* c, void* hip_stream)
   if (!c)
     return 0;
   enter(c);
+  if (c->capturing) {
+    c->err = "mifc_set_stream: a graph capture is open on this context (mifc_graph_begin)";
+    return 0;
+  }
   return switch_stream(c, static_cast<hipStream_t>(hip_stream)); // null = HIP's default stream
 }
 
@@ -535,6 +548,10 @@ int mifc_use_own_stream(mifc_ctx* c)
   if (!c)
     return 0;
   enter(c);
+  if (c->capturing) {
+    c->err = "mifc_use_own_stream: a graph capture is open on this context (mifc_graph_begin)";
+    return 0;
+  }
   return switch_stream(c, c->own_stream);
 }
 
@@ -680,6 +697,24 @@ float mifc_timing_end_ms(mifc_ctx* c)
     total += ms;
   }
   return c->n_timed >= mifc_ctx::NTIMED ? -1.f : total;
+}
+
+int mifc_counts_accumulate(mifc_ctx* c, int on)
+{
+  if (!c)
+    return 0;
+  c->counts_accumulate = on != 0;
+  return 1;
+}
+
+int mifc_zero_counts_enqueue(mifc_ctx* c, unsigned long long* counts_dev, size_t n)
+{
+  if (!c || !counts_dev)
+    return 0;
+  enter(c);
+  if (n)
+    MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, n * sizeof(u64), c->stream));
+  return 1;
 }
 
 int mifc_classify(unsigned long long n_undefined, unsigned long long n)
@@ -1673,7 +1708,8 @@ static int stencil_enqueue(mifc_ctx* c, const char* who, mifc::StencilParams& P,
       for (int l = 0; l < P.nlev; ++l)
         hf[l] = fdefined_in[l] == MIFC_ALL_DEFINED ? 1 : 0;
     }
-    MIFC_HIP(c, mifc::launch_prep_levels(upload ? hf.data() : nullptr, P.nlev, c->d_flags, n_undefined_dev, P.nlev, c->stream));
+    MIFC_HIP(c, mifc::launch_prep_levels(upload ? hf.data() : nullptr, P.nlev, c->d_flags, c->counts_accumulate ? nullptr : n_undefined_dev, P.nlev,
+                                         c->stream));
   } else {
     if (upload) {
       if (!pinned_acquire(c))
@@ -1684,7 +1720,7 @@ static int stencil_enqueue(mifc_ctx* c, const char* who, mifc::StencilParams& P,
       if (!pinned_release(c))
         return 0;
     }
-    if (n_undefined_dev)
+    if (n_undefined_dev && !c->counts_accumulate)
       MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64) * (size_t)P.nlev, c->stream));
   }
   MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
@@ -1900,7 +1936,8 @@ int derived_common(mifc_ctx* c, int nx, int ny, int nlev, const DerivedRequest& 
     P.thermo_all_defined = c->d_flags + c->cap_lev;
   }
   P.every_level_all_defined = every_all ? 1 : 0;
-  MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 5 * sizeof(u64) * (size_t)nlev, c->stream));
+  if (!(c->counts_accumulate && !prepared_only && counts_dev != c->d_counts)) // (accumulate mode: the caller zeroed its counters)
+    MIFC_HIP(c, hipMemsetAsync(counts_dev, 0, 5 * sizeof(u64) * (size_t)nlev, c->stream));
   if (prepared_only) { // the caller launches chunk by chunk (host pipeline)
     *prepared_only = P;
   } else {

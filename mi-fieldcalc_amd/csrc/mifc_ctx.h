@@ -48,6 +48,15 @@ struct mifc_ctx
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;
   bool comm_owned = false;
+  // mifc_counts_accumulate: the *_enqueue entries add to the caller's counters instead of zeroing them first
+  bool counts_accumulate = false;
+  // mifc_graph_begin .. mifc_graph_end: the *_enqueue calls in between are recorded on capture_stream instead of running
+  bool capturing = false;
+  hipStream_t capture_stream = nullptr, stream_before_capture = nullptr;
+  // lanes of a capture: independent calls recorded side by side (mifc_graph_lane); lane 0 is capture_stream
+  std::vector<hipStream_t> lane_streams;
+  std::vector<hipEvent_t> lane_events; // [0] fork, [k] join of lane k
+  int n_lanes = 1, lane = 0;
   // chunked, full-duplex streaming of host-resident level batches (created on first use)
   mifc::HostPipe* pipe = nullptr;
   // host fields the caller declared constant (mifc_hold_field): device copies that stage_in reuses

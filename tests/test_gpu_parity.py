@@ -743,6 +743,85 @@ def test_vortdiv_ff_levels_three_outputs_in_one_pass(gpu_ctx, oracle, nx, ny, nl
         assert (ALL if flags[l] == ALL else fc.classify(int(c[l]), nx * ny - 2 * nx)) == fo_e[l], (l, c[l], fo_e[l])
 
 
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_graph_of_per_level_calls_replays_on_new_input(oracle, lanes):
+    """mifc_graph_begin / _end / _launch: a caller's loop of one asynchronous call per level -- the stencil pair and the fused
+    derived batch, a level each -- recorded once and replayed on CHANGED inputs: every replay equals the per-level reference
+    calls.  With three lanes the levels are recorded side by side (counters zeroed once at the head of the graph,
+    mifc_counts_accumulate).  A synchronous call inside a capture invalidates it: mifc_graph_end says so, the context stays
+    usable.  Context.prepare repeats the same C calls without the wrapper."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny, nlev = 516, 40, 6
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    al, bl = synth.hybrid_levels(nlev)
+    with fc.Context(0) as ctx:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            dxm, dym = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+            du, dv = torch.zeros((nlev, ny, nx), device="cuda"), torch.zeros((nlev, ny, nx), device="cuda")
+            dt, dq, dps = torch.zeros_like(du), torch.zeros_like(du), torch.zeros((ny, nx), device="cuda")
+            rv, dg, ff, th, rh = (torch.empty_like(du) for _ in range(5))
+            cnt = torch.zeros(nlev, dtype=torch.int64, device="cuda")
+            cnt5 = torch.zeros(5 * nlev, dtype=torch.int64, device="cuda")
+            some = np.full(1, SOME, np.int32)
+
+            def per_level(g=None):
+                for l in range(nlev):
+                    if g is not None and lanes > 1:
+                        g.lane(l % lanes)
+                    assert ctx.stencil_levels_enqueue("vortdiv", du[l:l + 1], dv[l:l + 1], dxm, dym, None, rv[l:l + 1], dg[l:l + 1], fdefined=some,
+                                                      n_undefined=cnt[l:l + 1])
+                    ctx.hlevel_derived_batch(du[l:l + 1], dv[l:l + 1], dt[l:l + 1], dq[l:l + 1], dps, al[l:l + 1], bl[l:l + 1], temp=("", 3), hum=("", 1),
+                                             fdef_wind=some, fdef_thermo=some, out={"ff": ff[l:l + 1], "temp": th[l:l + 1], "hum": rh[l:l + 1]},
+                                             enqueue_counts=cnt5[5 * l:5 * l + 5])
+
+            with ctx.graph_capture(max_levels_per_call=8, lanes=lanes) as g:
+                if lanes > 1:
+                    ctx.zero_counts_enqueue(cnt)
+                    ctx.zero_counts_enqueue(cnt5)
+                    ctx.counts_accumulate(True)
+                per_level(g)
+                ctx.counts_accumulate(False)
+            prepared = ctx.prepare(per_level)
+            assert len(prepared) == 2 * nlev
+            for it, runner in enumerate((g.launch, g.launch, prepared.launch)):
+                u, v = synth.wind(nx, ny, 700 + it, nlev=nlev)
+                u[it] = synth.sprinkle_undef(u[it], it, 0.02)
+                du.copy_(torch.from_numpy(u))
+                dv.copy_(torch.from_numpy(v))
+                t, q, ps = (x.cpu().numpy() for x in synth.device_thermo(nx, ny, nlev, 800 + it, "cuda"))
+                dt.copy_(torch.from_numpy(t))
+                dq.copy_(torch.from_numpy(q))
+                dps.copy_(torch.from_numpy(ps))
+                runner()
+                torch.cuda.synchronize()
+                c = cnt.cpu().numpy()
+                for l in range(nlev):
+                    ok, e, f = oracle.call("relvort", nx, ny, u[l], v[l], xm, ym, fdefined=SOME)
+                    assert cases.same_bits(rv[l].cpu().numpy(), e, nan_payload=False) and fc.classify(int(c[l]), nx * ny - 2 * nx) == f, (it, l)
+                    ok, e, f = oracle.call("divergence", nx, ny, u[l], v[l], xm, ym, fdefined=SOME)
+                    assert cases.same_bits(dg[l].cpu().numpy(), e, nan_payload=False), (it, l)
+                    ok, e, f = oracle.call("vectorabs", nx, ny, u[l], v[l], fdefined=SOME)
+                    assert cases.same_bits(ff[l].cpu().numpy(), e, nan_payload=False) and fc.classify(int(cnt5[5 * l]), nx * ny) == f, (it, l)
+                    ok, e, f = oracle.call("hleveltemp", nx, ny, t[l], ps, float(al[l]), float(bl[l]), "", 3, fdefined=SOME)
+                    got = th[l].cpu().numpy()
+                    assert np.all(np.abs(got.astype(np.float64) - e) <= 1e-5 * np.abs(e)), (it, l)
+            g.close()
+            # a synchronous entry point cannot be recorded
+            with pytest.raises(RuntimeError):
+                with ctx.graph_capture() as bad:
+                    try:
+                        ctx.relvort(du[0], dv[0], dxm, dym, fdefined=SOME)
+                    except RuntimeError:
+                        pass
+            res = ctx.relvort(du[0], dv[0], dxm, dym, fdefined=SOME)  # ... and the context is still usable
+            assert res is not None and torch.equal(res[0].view(torch.int32), rv[0].view(torch.int32))
+
+
 def test_stencil_levels_enqueue_equals_the_synchronous_call(gpu_ctx, oracle):
     """mifc_stencil_levels_enqueue (nothing read back; counts stay on the device) against mifc_stencil_levels: same fields bit
     for bit, and classify(count, mifc_stencil_count_domain) gives the flags -- plevelgwind_xcomp excepted, which is
