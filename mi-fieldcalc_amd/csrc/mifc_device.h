@@ -532,7 +532,7 @@ __device__ __forceinline__ float f_diverg(float xm, float ym, float dudx, float 
 //   dd = 270 - atan2(v, u) * 180 / pi, brought into [0, 360); calm (u == v == 0) gives 0.
 // Evaluated in float as dd = atan2(-u, -v) * 180 / pi (+360 when negative): the same angle as 270 - atan2(v, u) * 180 / pi
 // without the subtraction, whose cancellation near north (dd -> 0) cost all relative accuracy (round 2: 2e-3 degrees
-// absolute).  Now within 1e-5 RELATIVE of the float64 definition rounded once (oracle/mifc_oracle.cc: mifcorc_winddir)
+// absolute).  Now within 1e-5 RELATIVE of the float64 definition rounded once (the test suite's CPU restatement)
 // everywhere; the definition, not a reference result, is what the tests pin.
 __device__ __forceinline__ float wind_direction(float u, float v)
 {
