@@ -94,16 +94,22 @@ __device__ __forceinline__ void lds_rows_visible()
 {
   asm volatile("" ::: "memory");
 }
-// {west, own four, east} of a ring row
+// {west, own four, east} of a ring row: the lane's own column group from LDS, the two x-neighbours from the ADJACENT LANES'
+// groups (wave shifts).  Round 2 read them from LDS as scalars (row[p - 1], row[p + 4]): 64 lanes 16 bytes apart hit each
+// bank four times -- 58 % of this kernel's LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE,
+// profiles/r02/experiments/sq_counters_two_stage_kernels_end.txt).  Every lane whose group a NEIGHBOUR needs must be active
+// here (a disabled source lane leaves the destination as it is): the callers run this for all lanes that hold a group,
+// the halo groups included, and select the lanes that compute afterwards.  The outermost groups keep their own edge value
+// as the missing neighbour: it only reaches cells whose values are fill copies and whose counts the edge kernel takes.
 __device__ __forceinline__ void row6(const float* row, int p, float (&v)[6])
 {
   const float4 q = ld4(row + p);
-  v[0] = row[p - 1];
+  v[0] = from_lower_lane(q.x, q.w);
   v[1] = q.x;
   v[2] = q.y;
   v[3] = q.z;
   v[4] = q.w;
-  v[5] = row[p + 4];
+  v[5] = from_upper_lane(q.w, q.x);
 }
 
 // ---- undefined values as NaN inside the tiles of the tested TFP variant
@@ -422,19 +428,30 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
       t_east = from_upper_lane(0.f, tx_first);
     }
     float o[4] = {undef, undef, undef, undef};
+    // the rows whose x-neighbours stage B needs: read by every lane that holds a group (the owned groups' neighbours come
+    // from the adjacent lanes, row6), before the owned lanes are selected
+    float mid6a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, mid6b[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool row_b = j >= jb0 && j < jb1; // wave-uniform
+    if (row_b && lane < TQ) {
+      row6(mid0 + (j % 3) * TS, p, mid6a); // |grad tx| | ug
+      if (TFP)
+        row6(ringA + (j % RA) * TS, p, mid6b); // tx
+      else
+        row6(mid1 + (j % 3) * TS, p, mid6b); // vg
+    }
     if (have_row) {
       const int js = (j - 1 < 1) ? 1 : j - 1, jn = (j + 1 > ny - 2) ? ny - 2 : j + 1; // filled intermediate rows 0 / ny-1 are rows 1 / ny-2
       float xm[4], ym[4];
       unpack(m_b.xm, xm);
       unpack(m_b.ym, ym);
       if (TFP) {
-        float gs[4], gn[4], gc[6], ts[4], tn[4], tc[6];
+        float gs[4], gn[4], ts[4], tn[4];
+        const float(&gc)[6] = mid6a;
+        const float(&tc)[6] = mid6b;
         unpack(ld4(mid0 + (js % 3) * TS + p), gs);
         unpack(ld4(mid0 + (jn % 3) * TS + p), gn);
-        row6(mid0 + (j % 3) * TS, p, gc);
         unpack(ld4(ringA + ((j - 1) % RA) * TS + p), ts);
         unpack(ld4(ringA + ((j + 1) % RA) * TS + p), tn);
-        row6(ringA + (j % RA) * TS, p, tc);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           bool ok, by_test;
@@ -449,13 +466,13 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
           }
         }
       } else {
-        float us[4], un[4], uc[6], vs[4], vn[4], vc[6], ts[4], tn[4], tc[6];
+        float us[4], un[4], vs[4], vn[4], ts[4], tn[4], tc[6];
+        const float(&uc)[6] = mid6a;
+        const float(&vc)[6] = mid6b;
         unpack(ld4(mid0 + (js % 3) * TS + p), us);
         unpack(ld4(mid0 + (jn % 3) * TS + p), un);
-        row6(mid0 + (j % 3) * TS, p, uc);
         unpack(ld4(mid1 + (js % 3) * TS + p), vs);
         unpack(ld4(mid1 + (jn % 3) * TS + p), vn);
-        row6(mid1 + (j % 3) * TS, p, vc);
         unpack(t_south, ts);
         unpack(m_a.t, tn);
         tc[0] = t_west;
