@@ -160,14 +160,20 @@ class Context:
         if not self._lib.mifc_synchronize(self._ctx):
             raise RuntimeError(self.last_error())
 
+    def _measure_entry(self, name):
+        fn = getattr(self._lib, name, None)
+        if fn is None:
+            raise RuntimeError("%s exists in the measurement build of the library only (tools/ select it through MIFC_LIB_PATH)" % name)
+        return fn
+
     def timing_begin(self):
-        """Measurement aid: bracket every kernel launch of the following calls with HIP events."""
-        if not self._lib.mifc_timing_begin(self._ctx):
+        """Measurement build only: bracket every kernel launch of the following calls with HIP events."""
+        if not self._measure_entry("mifc_timing_begin")(self._ctx):
             raise RuntimeError(self.last_error())
 
     def timing_end_ms(self):
         """Summed kernel time (ms) of the calls since timing_begin(); -1 if unavailable."""
-        return float(self._lib.mifc_timing_end_ms(self._ctx))
+        return float(self._measure_entry("mifc_timing_end_ms")(self._ctx))
 
     def hold_field(self, host_array):
         """Uploads a constant host field (map ratios, Coriolis parameter) once;
@@ -867,12 +873,14 @@ class Context:
         return bool(self._call("mifc_halo_copy_enqueue", [dst.data_ptr(), src_ctx._ctx, src.data_ptr(), dst.numel()]))
 
     def diag_division(self, a, b, g, shared, plain):
-        """Arithmetic self-check (see include/mifc.h); device tensors of equal length."""
+        """Measurement build only (include/mifc_measure.h): arithmetic self-check; device tensors of equal length."""
+        self._measure_entry("mifc_diag_division")
         self._bind_stream(MEM_DEVICE)
         return bool(self._call("mifc_diag_division", [a.data_ptr(), b.data_ptr(), g.data_ptr(), shared.data_ptr(), plain.data_ptr(), a.numel()]))
 
     def bench_stream2(self, variant, blocks, dst0, dst1, src0, src1):
-        """Bandwidth yardstick (see include/mifc.h); device tensors."""
+        """Measurement build only (include/mifc_measure.h): bandwidth yardstick; device tensors."""
+        self._measure_entry("mifc_bench_stream2")
         self._bind_stream(MEM_DEVICE)
         n = src0.numel()
         return bool(self._call("mifc_bench_stream2", [int(variant), int(blocks), dst0.data_ptr(), dst1.data_ptr(), src0.data_ptr(), src1.data_ptr(), n]))

@@ -47,8 +47,6 @@ SIGNATURES = {
     "mifc_batch_free_placed": ("i", ["ctx", "p", "i"]),
     "mifc_hold_field": ("i", ["ctx", "p", "z"]),
     "mifc_release_field": ("i", ["ctx", "p"]),
-    "mifc_timing_begin": ("i", ["ctx"]),
-    "mifc_timing_end_ms": ("fl", ["ctx"]),
     "mifc_classify": ("i", ["u64", "u64"]),
     "mifc_counts_accumulate": ("i", ["ctx", "i"]),
     "mifc_zero_counts_enqueue": ("i", ["ctx", "pu", "z"]),
@@ -173,7 +171,14 @@ SIGNATURES = {
     "mifc_slab_plan_uses_graph": ("i", ["p"]),
     "mifc_slab_plan_begin": ("i", ["p"]),
     "mifc_slab_plan_finish": ("i", ["p"]),
-    # diagnostics
+}
+
+
+# entry points of the measurement build only (include/mifc_measure.h): bound when the loaded library has them, i.e. when
+# MIFC_LIB_PATH points a tool at the measurement build
+MEASURE_SIGNATURES = {
+    "mifc_timing_begin": ("i", ["ctx"]),
+    "mifc_timing_end_ms": ("fl", ["ctx"]),
     "mifc_bench_stream2": ("i", ["ctx", "i", "i", "p", "p", "p", "p", "z"]),
     "mifc_diag_division": ("i", ["ctx", "p", "p", "p", "p", "p", "z"]),
 }
@@ -199,6 +204,11 @@ def load_library(path=LIB_PATH):
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = _T[res] if res else None
         fn.argtypes = [_T[a] for a in args]
+    for name, (res, args) in MEASURE_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = _T[res] if res else None
+            fn.argtypes = [_T[a] for a in args]
     return lib
 
 

@@ -668,6 +668,7 @@ int mifc_release_field(mifc_ctx* c, const float* host_field)
   return 0;
 }
 
+#ifdef MIFC_MEASUREMENT_BUILD // libmifc_measure.so only (include/mifc_measure.h)
 // Measurement aid: between begin and end every kernel launch of this context is bracketed by a
 // HIP event pair on its launch stream; end returns the summed kernel time in milliseconds
 // (-1 on error, or when more than 16 launches happened in between).
@@ -698,6 +699,7 @@ float mifc_timing_end_ms(mifc_ctx* c)
   }
   return c->n_timed >= mifc_ctx::NTIMED ? -1.f : total;
 }
+#endif // MIFC_MEASUREMENT_BUILD
 
 int mifc_counts_accumulate(mifc_ctx* c, int on)
 {
@@ -2240,6 +2242,7 @@ int mifc_halo_copy_enqueue(mifc_ctx* dst_ctx, float* dst_dev, mifc_ctx* src_ctx,
   return 1;
 }
 
+#ifdef MIFC_MEASUREMENT_BUILD // libmifc_measure.so only (include/mifc_measure.h)
 int mifc_bench_stream2(mifc_ctx* c, int variant, int blocks, float* dst0, float* dst1, const float* src0, const float* src1, size_t n_floats)
 {
   if (!c)
@@ -2259,5 +2262,6 @@ int mifc_diag_division(mifc_ctx* c, const float* a, const float* b, const float*
   MIFC_HIP(c, mifc::launch_division_check(a, b, g, shared, plain, n, c->stream));
   return 1;
 }
+#endif // MIFC_MEASUREMENT_BUILD
 
 } // extern "C"

@@ -98,7 +98,8 @@ inline void enter(mifc_ctx* c)
     }                                        \
   } while (0)
 
-// launches wrapped in event pairs while a timing section is open
+// launches wrapped in event pairs while a timing section is open (mifc_timing_begin: the measurement build only)
+#ifdef MIFC_MEASUREMENT_BUILD
 #define MIFC_LAUNCH(c, call)                                                      \
   do {                                                                            \
     const bool timed_ = (c)->timing && (c)->n_timed < mifc_ctx::NTIMED;           \
@@ -110,6 +111,9 @@ inline void enter(mifc_ctx* c)
       (c)->n_timed += 1;                                                          \
     }                                                                             \
   } while (0)
+#else
+#define MIFC_LAUNCH(c, call) MIFC_HIP(c, call)
+#endif
 
 bool ensure_slot(mifc_ctx* c, int s, size_t bytes);
 bool ensure_levels(mifc_ctx* c, size_t nlev);

@@ -360,6 +360,7 @@ hipError_t launch_ewise(const EwiseParams& prm, hipStream_t stream)
 
 } // namespace mifc
 
+#ifdef MIFC_MEASUREMENT_BUILD // libmifc_measure.so only (tools/): the bandwidth yardsticks are not part of the product
 // ----------------------------------------------------------------------------
 // Bandwidth yardstick (diagnostic): streams two input fields into two output
 // fields with the same 16-byte-per-lane access shape as the operators and no
@@ -587,3 +588,4 @@ hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const f
   return hipGetLastError();
 }
 } // namespace mifc
+#endif // MIFC_MEASUREMENT_BUILD

@@ -532,6 +532,7 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
   wave_count_add(P.counts + 1, n2);
 }
 
+#ifdef MIFC_MEASUREMENT_BUILD // libmifc_measure.so only
 // diagnostic: the same quotient through shared_reciprocal()/quotient() and through the compiler's a / b
 __global__ void division_check_kernel(const float* a, const float* b, const float* g, float* shared, float* plain, size_t n)
 {
@@ -541,6 +542,7 @@ __global__ void division_check_kernel(const float* a, const float* b, const floa
     plain[i] = (float)(num / den);
   }
 }
+#endif
 
 bool aligned16(const void* p)
 {
@@ -601,11 +603,13 @@ hipError_t launch_op(const Fused2Params& p, hipStream_t stream)
 
 } // namespace
 
+#ifdef MIFC_MEASUREMENT_BUILD
 hipError_t launch_division_check(const float* a, const float* b, const float* g, float* shared, float* plain, size_t n, hipStream_t stream)
 {
   hipLaunchKernelGGL(division_check_kernel, dim3(1024), dim3(256), 0, stream, a, b, g, shared, plain, n);
   return hipGetLastError();
 }
+#endif
 
 bool fused2_supported(const Fused2Params& p)
 {

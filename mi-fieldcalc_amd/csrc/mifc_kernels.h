@@ -326,11 +326,13 @@ struct Fused2Params
 bool fused2_supported(const Fused2Params& prm);
 hipError_t launch_fused2(const Fused2Params& prm, hipStream_t stream);
 
+#ifdef MIFC_MEASUREMENT_BUILD // libmifc_measure.so only
 // diagnostic: (0.5*a*b*g0)/g through the shared-reciprocal quotient of mifc_device.h and through a plain f64 division
 hipError_t launch_division_check(const float* a, const float* b, const float* g, float* shared, float* plain, size_t n, hipStream_t stream);
 
 // diagnostic: two-in / two-out streaming copy (bandwidth yardstick)
 hipError_t launch_stream2(int variant, int blocks, float* d0, float* d1, const float* s0, const float* s1, size_t n_floats, hipStream_t stream);
+#endif
 
 } // namespace mifc
 

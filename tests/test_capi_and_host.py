@@ -340,6 +340,12 @@ def test_measurement_knobs_exist_in_the_measurement_build_only(built):
     for key in (b"PADROWS", b"MIFC_MEASUREMENT_KNOBS"):
         assert key not in product, key
     assert b"PADROWS" in measure
+    # round 3: the yardsticks, the division self-check and the per-launch event timing too (include/mifc_measure.h)
+    out = {which: subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout for which, path in
+           (("product", LIB), ("measure", measure_path))}
+    for sym in ("mifc_timing_begin", "mifc_timing_end_ms", "mifc_bench_stream2", "mifc_diag_division"):
+        assert (" T " + sym) not in out["product"] and (" T " + sym) in out["measure"], sym
+    assert "stream2_kernel" not in out["product"] and b"stream2_kernel" not in product
     pkg = os.path.join(ROOT, "mi-fieldcalc_amd")
     for f in os.listdir(pkg):
         if f.endswith(".py"):

@@ -15,6 +15,7 @@ import cases
 import golden_util
 import gpu_util
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 ALL, NONE, SOME = cases.ALL_DEFINED, cases.NONE_DEFINED, cases.SOME_DEFINED
@@ -941,7 +942,7 @@ def test_fused_tfp_and_qvector(gpu_ctx, oracle, fused, device, mifc_env):
         _check_case(gpu_ctx, oracle, case, device=device)
 
 
-def test_shared_reciprocal_division_is_the_plain_division(gpu_ctx):
+def test_shared_reciprocal_division_is_the_plain_division():
     """The fused kernels divide two numerators by one denominator through one refined reciprocal
     (csrc/mifc_device.h); for float-born operands that must be the f64 division, bit for bit --
     including zeros, infinities, NaNs, denormals and the ends of the float range."""
@@ -962,7 +963,19 @@ def test_shared_reciprocal_division_is_the_plain_division(gpu_ctx):
     ops[1][: special.numel() ** 2] = 1.0
     shared = torch.empty(n, device="cuda")
     plain = torch.empty(n, device="cuda")
-    assert gpu_ctx.diag_division(ops[0], ops[1], ops[2], shared, plain)
+    # mifc_diag_division lives in the measurement build (include/mifc_measure.h): the same device functions, compiled from the
+    # same header, in libmifc_measure.so -- loaded here next to the product library, with a context of its own
+    import ctypes
+
+    measure = ctypes.CDLL(os.path.join(ROOT, "mi-fieldcalc_amd", "libmifc_measure.so"))
+    measure.mifc_create.restype = ctypes.c_void_p
+    mctx = ctypes.c_void_p(measure.mifc_create(0))
+    assert mctx.value
+    torch.cuda.synchronize()
+    ok = measure.mifc_diag_division(mctx, *[ctypes.c_void_p(t.data_ptr()) for t in (ops[0], ops[1], ops[2], shared, plain)], ctypes.c_size_t(n))
+    measure.mifc_synchronize(mctx)
+    measure.mifc_destroy(mctx)
+    assert ok
     torch.cuda.synchronize()
     s, p = shared.cpu().numpy(), plain.cpu().numpy()
     assert cases.same_bits(s, p, nan_payload=False)

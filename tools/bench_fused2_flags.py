@@ -1,6 +1,7 @@
 """Kernel time of the fused thermalFrontParameter / plevelqvector launch on the 1440x98640 tall field with an
 ALL_DEFINED and a SOME_DEFINED input flag (the latter runs the tested variant and the edge-count workgroups)."""
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, '.')
+os.environ.setdefault("MIFC_LIB_PATH", os.path.join(os.getcwd(), "mi-fieldcalc_amd", "libmifc_measure.so"))  # measurement build
 import numpy as np, torch
 import mi_fieldcalc_amd as fc, mi_fieldcalc_amd.synth as synth
 NX, NY, NLEV = 1440, 720, 137

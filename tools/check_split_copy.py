@@ -1,4 +1,5 @@
-import sys; sys.path.insert(0, '.')
+import os, sys; sys.path.insert(0, '.')
+os.environ.setdefault("MIFC_LIB_PATH", os.path.join(os.getcwd(), "mi-fieldcalc_amd", "libmifc_measure.so"))  # measurement build
 import torch, mi_fieldcalc_amd as fc
 ctx = fc.Context(0)
 for n in (1440*720*3, 1000*4+ 4*77, 256*4*4096*2 + 4*5):
