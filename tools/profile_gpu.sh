@@ -12,8 +12,8 @@ export TMPDIR=/tmp
 # the probe launches of the placement search (other arrays, 0-12 % slower): the search is cut to 48 probes here
 # (~830 dispatches next to the 6 000 of the timed region and the per-launch pairs), and tools/summarize_prof.py
 # also averages the LAST dispatches of the kernel trace alone (all on the chosen batch).  The counter passes skip the search: the bytes a launch moves do not depend on where the arrays lie.
-CMD="python3 bench.py --steps 3000 --warmup 5 --no-cpu-baseline --no-verify --no-check-variant --placement-tries 48"
-PMC_CMD="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-verify --no-check-variant --placement-pool 0"
+CMD="python3 bench.py --steps 3000 --warmup 5 --no-cpu-baseline --no-verify --no-check-variant --no-as-allocated --placement-tries 48"
+PMC_CMD="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-verify --no-check-variant --no-as-allocated --placement-pool 0"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $CMD > "$OUT/trace.log" 2>&1
 echo "trace rc=$?"

@@ -20,9 +20,9 @@ cat "$O/box.txt"
 python3 bench.py --steps 20 --warmup 5 > "$O/bench_n1.json" 2> "$O/bench_n1.err"
 echo "bench rc=$?"; cat "$O/bench_n1.json"
 echo "# five consecutive processes of 'python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline' on ONE box, same binary" > "$O/bench_repeat.txt"
-echo "# Mcells/s  ms_per_step(wall)  kernel_ms_avg(HIP events)  roofline.frac  tested-variant frac  verified  chosen ms per placement pool" >> "$O/bench_repeat.txt"
+echo "# Mcells/s  ms_per_step(wall)  kernel_ms_avg(HIP events)  roofline.frac  tested-variant frac (median of 5 bursts)  as-allocated frac  verified  chosen ms per placement pool  tested-variant bursts (ms)" >> "$O/bench_repeat.txt"
 for i in 1 2 3 4 5; do
-  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'], d.get('check_variant',{}).get('roofline_frac'), d['verified'], d['config']['placement'].get('rounds_chosen_ms'))" >> "$O/bench_repeat.txt"
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.readline()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_ms_avg'], d['roofline']['frac'], d.get('check_variant',{}).get('roofline_frac'), (d.get('roofline_as_allocated') or {}).get('frac'), d['verified'], d['config']['placement'].get('rounds_chosen_ms'), d.get('check_variant',{}).get('bursts_ms'))" >> "$O/bench_repeat.txt"
 done
 cat "$O/bench_repeat.txt"
 W="K=3,RB=12,LG=6,ZZ=1,D=0"   # the level-walking kernel whose waves load and store (MIFC_VORTDIV_SPLIT=0); the measurement knobs exist for it
