@@ -276,12 +276,13 @@ int shape_value(const char* s, const char* key, int dflt)
 //     15 waves all behave so, 12 and 16 do not) -- which suits the operators bound by memory: one workgroup per CU streaming
 //     three levels ahead is the access pattern of the headline kernel, 2-5 % faster than two workgroups per CU.
 //   * {14 rows, 2 loaders, 2 levels ahead}: 16-wave workgroups, two per CU, for the variants bound by instruction issue --
-//     |grad f| (a correctly rounded square root) and everything that tests its inputs but ilevelgwind and d/dy, whose
-//     arithmetic phases then overlap (the 14-wave shape runs them 15-25 % slower).
+//     |grad f| (a correctly rounded square root), the Laplacian, plevelgvort (fp64 chains) and everything that tests its
+//     inputs but d/dy, whose arithmetic phases then overlap (the 14-wave shape runs the tested ones 15-25 % slower;
+//     profiles/r03/split_role_ops_placed.txt has both shapes for every operator on one set of placed arrays).
 // MIFC_SCALAR_SPLIT_TUNE="TR=12,NL=2,PF=2,LG=6" overrides (A/B measurements and tests; only the shapes instantiated below exist).
 SplitShape current_shape(int op, bool check)
 {
-  const bool issue_bound = op == ST_GRAD_ABS || (check && op != ST_IGWIND && op != ST_GRAD_Y);
+  const bool issue_bound = op == ST_GRAD_ABS || op == ST_GRAD_LAP || op == ST_GVORT || (check && op != ST_GRAD_Y);
   SplitShape sh = issue_bound ? SplitShape{14, 2, 2, 0} : SplitShape{12, 2, 3, 0};
   const char* s = env().scalar_split_tune;
   if (s[0]) {
