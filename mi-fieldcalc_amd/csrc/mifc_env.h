@@ -25,6 +25,7 @@ struct Env
   bool levelwalk = true;          // MIFC_VORTDIV_LEVELWALK=0: deep wind batches on the row-walking kernel (A/B)
   bool split_roles = true;        // MIFC_VORTDIV_SPLIT=0: deep batches of the stencil operators on the level-walking kernels whose waves load AND store (A/B)
   int levelwalk_min_units = 0;    // MIFC_LEVELWALK_MIN_UNITS (> 0 overrides the launch size from which the level-walking forms are chosen; tests)
+  bool ragged_split = true;       // MIFC_RAGGED_SPLIT=0: widths that are not a multiple of 4 keep the flat four-cells-per-lane kernel for deep batches too (A/B)
   bool slab_graph = true;         // MIFC_SLAB_GRAPH=0: the row-slab step (mifc_slab_plan_step) enqueues its sequence directly instead of replaying a HIP graph
   bool has_vortdiv_tune = false;  // MIFC_VORTDIV_TUNE="R=8,D=1,..."
   char vortdiv_tune[256] = {0};

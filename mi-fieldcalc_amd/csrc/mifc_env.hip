@@ -54,6 +54,7 @@ void env_reload()
   e.split_roles = not_zero("MIFC_VORTDIV_SPLIT");
   e.levelwalk_min_units = positive_int("MIFC_LEVELWALK_MIN_UNITS");
   e.slab_graph = not_zero("MIFC_SLAB_GRAPH");
+  e.ragged_split = not_zero("MIFC_RAGGED_SPLIT");
   if (const char* s = std::getenv("MIFC_VORTDIV_TUNE")) {
     e.has_vortdiv_tune = true;
     std::strncpy(e.vortdiv_tune, s, sizeof e.vortdiv_tune - 1);

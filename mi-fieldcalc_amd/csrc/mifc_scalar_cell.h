@@ -22,6 +22,7 @@ struct SRowsParams
   const unsigned char* all_defined;
   float undef;
   u64* n_undefined;
+  int ragged; // split-role form only: rows at any alignment (a width that is not a multiple of 4, unaligned fields or level strides)
 };
 
 namespace {
@@ -214,7 +215,7 @@ __device__ __forceinline__ bool scalar_cell_hoisted(bool all, float undef, float
 } // namespace
 
 // split-role level-walking form (mifc_stencil_split.hip); rp.uB / rp.uW / rp.wpb / rp.n_logical / rp.per_xcd are set by it
-bool scalar_split_applies(int op, int nx, int ny, int nlev, bool check, float undef);
+bool scalar_split_applies(int op, int nx, int ny, int nlev, bool check, float undef, bool ragged);
 hipError_t launch_scalar_split(int op, SRowsParams& rp, bool check, hipStream_t stream);
 
 } // namespace mifc

@@ -531,7 +531,54 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   if (op < ST_GRAD_X || op > ST_IGWIND)
     return hipSuccess;
   const int nx = prm.nx, ny = prm.ny_global;
-  if (prm.j0 != 0 || prm.ny_local != ny || nx % 4 != 0 || nx < 8 || ny < 3)
+  if (prm.j0 != 0 || prm.ny_local != ny || nx < 8 || ny < 3)
+    return hipSuccess;
+  // Rows at any alignment (a width that is not a multiple of 4, fields or level strides off the 16-byte grid): the
+  // split-role level-walking form has a variant for them (RAGGED, mifc_stencil_split.hip); the other forms of this file
+  // do not, and such a call outside that form's range goes to the flat kernels.
+  {
+    const bool uxm = (op != ST_GRAD_Y && op != ST_GWIND_X), uym = (op != ST_GRAD_X && op != ST_GWIND_Y);
+    const bool ufc = (op == ST_GWIND_X || op == ST_GWIND_Y || op == ST_GVORT || op == ST_IGWIND);
+    const bool present = prm.f0 && prm.out0 && (!uxm || prm.xmapr) && (!uym || prm.ymapr) && (!ufc || prm.fcoriolis) && (op != ST_IGWIND || prm.out1);
+    const bool ragged = nx % 4 != 0 || !a16(prm.f0) || !a16(prm.out0) || (uxm && !a16(prm.xmapr)) || (uym && !a16(prm.ymapr)) || (ufc && !a16(prm.fcoriolis)) ||
+                        (op == ST_IGWIND && !a16(prm.out1)) || prm.in_level_stride % 4 != 0 || prm.out_level_stride % 4 != 0;
+    if (present && ragged) {
+      const bool check = !prm.every_level_all_defined;
+      // (nx % 256 == 1: the column whose value fillEdges copies into column nx-1 belongs to another workgroup)
+      if (nx % 256 == 1 || env().force_cell_kernel || env().scalar_rows_r >= 0 || !scalar_split_applies(op, nx, ny, prm.nlev, check, prm.undef, true))
+        return hipSuccess;
+      SRowsParams rp{};
+      rp.nx = nx;
+      rp.ny = ny;
+      rp.nlev = prm.nlev;
+      rp.f = prm.f0;
+      rp.xm = prm.xmapr;
+      rp.ym = prm.ymapr;
+      rp.fc = prm.fcoriolis;
+      rp.o0 = prm.out0;
+      rp.o1 = prm.out1;
+      rp.in_stride = prm.in_level_stride;
+      rp.out_stride = prm.out_level_stride;
+      rp.all_defined = prm.all_defined;
+      rp.undef = prm.undef;
+      rp.n_undefined = prm.n_undefined;
+      rp.ragged = 1;
+      *handled = true;
+      const hipError_t e = launch_scalar_split(op, rp, check, stream);
+      if (e == hipSuccess && op == ST_GRAD_X && check && rp.n_undefined) {
+        for (int l0 = 0; l0 < prm.nlev; l0 += 65535) { // grid.y limit; see count_outer_rows below
+          SRowsParams cp = rp;
+          const int nl = prm.nlev - l0 > 65535 ? 65535 : prm.nlev - l0;
+          cp.f = rp.f + (size_t)l0 * rp.in_stride;
+          cp.all_defined = rp.all_defined ? rp.all_defined + l0 : nullptr;
+          cp.n_undefined = rp.n_undefined + l0;
+          hipLaunchKernelGGL(gradx_outer_rows_count_kernel, dim3((unsigned)((2 * (nx - 1) + 255) / 256), (unsigned)nl), dim3(256), 0, stream, cp);
+        }
+      }
+      return e != hipSuccess ? e : hipGetLastError();
+    }
+  }
+  if (nx % 4 != 0)
     return hipSuccess;
   // gradient compute 1 counts over the flat range [1, nx*ny-1), i.e. also in rows 0 and ny-1, which the row kernels
   // do not walk: gradx_outer_rows_count_kernel adds those cells' share behind the main launch (values there are fill copies)
@@ -548,7 +595,7 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   if (env().force_cell_kernel)
     return hipSuccess;
 
-  SRowsParams rp;
+  SRowsParams rp{};
   const int V = (nx > 256) ? 2 : 1;
   rp.nx = nx;
   rp.ny = ny;
@@ -597,7 +644,8 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   // a small launch (fewer than 2048 waves even with 8-row bands) takes the one-shot form, and so do one or
   // two levels of any size: their row-walking workgroups would be single waves holding a 48-KiB tile of map
   // factors, three to a CU
-  if (forced_r < 0 && ((long)prm.nlev * ((ny - 2 + 7) / 8) * rp.nwc < 2048 || prm.nlev <= 2)) {
+  // (MIFC_LEVELWALK_MIN_UNITS, the tests' switch, sends launches of any size to the level-walking forms)
+  if (forced_r < 0 && ((env().levelwalk_min_units <= 0 && (long)prm.nlev * ((ny - 2 + 7) / 8) * rp.nwc < 2048) || prm.nlev <= 2)) {
     rp.uB = (ny - 2 + 3) / 4;
     rp.uW = (nx + 255) / 256;
     const long units = (long)prm.nlev * rp.uB * rp.uW;
@@ -644,7 +692,7 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   };
   // Deep batches, round 3: the level-walking tiles with split roles (mifc_stencil_split.hip) -- loader waves fill LDS two
   // levels ahead, compute waves only read LDS and store, two workgroups per CU -- for every operator of the family.
-  if (form != 0 && forced_r < 0 && scalar_split_applies(op, nx, ny, prm.nlev, check, prm.undef)) {
+  if (form != 0 && forced_r < 0 && scalar_split_applies(op, nx, ny, prm.nlev, check, prm.undef, false)) {
     const hipError_t e = launch_scalar_split(op, rp, check, stream);
     if (e == hipSuccess && op == ST_GRAD_X)
       count_outer_rows();

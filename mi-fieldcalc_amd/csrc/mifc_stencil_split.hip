@@ -29,14 +29,42 @@ namespace mifc {
 
 namespace {
 
-template <int OP, bool CHECK, int TR, int NL, int PF>
+// RAGGED: any width, dword-aligned fields (see vortdiv_split_kernel, mifc_vortdiv.hip: rows start wherever they start; the loads
+// do not care, the stores are 16-byte stores at dword alignment -- 75 % of the aligned store rate --, the last column group of
+// a row may be partial, and the one group that would read past the end of the batch is loaded cell by cell).
+struct __attribute__((packed, aligned(4))) V4Any
+{
+  v4f v;
+};
+__device__ __forceinline__ void st4_any_alignment(float* p, const float (&z)[4], int nvalid)
+{
+  if (nvalid >= 4) {
+    V4Any t;
+    t.v.x = z[0];
+    t.v.y = z[1];
+    t.v.z = z[2];
+    t.v.w = z[3];
+    *reinterpret_cast<V4Any*>(p) = t;
+  } else {
+    if (nvalid > 0)
+      p[0] = z[0];
+    if (nvalid > 1)
+      p[1] = z[1];
+    if (nvalid > 2)
+      p[2] = z[2];
+  }
+}
+
+template <int OP, bool CHECK, int TR, int NL, int PF, bool RAGGED = false>
 __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 3) / 4 : 1) void scalar_split_kernel(const SRowsParams P)
 {
   constexpr bool USE_XM = (OP != ST_GRAD_Y && OP != ST_GWIND_X);
   constexpr bool USE_YM = (OP != ST_GRAD_X && OP != ST_GWIND_Y);
   constexpr bool USE_FC = (OP == ST_GWIND_X || OP == ST_GWIND_Y || OP == ST_GVORT || OP == ST_IGWIND);
   constexpr bool TWO_OUT = (OP == ST_IGWIND);
-  constexpr bool NEED_X = USE_XM; // the operator reads the x-neighbours, hence the edge scalars
+  // the operator reads the x-neighbours, hence the edge scalars: in its formula, or -- plevelgwind_xcomp -- only in its test
+  // ("check for y component input, too", FieldCalculations.cc:659-660)
+  constexpr bool NEED_X = USE_XM || (CHECK && OP == ST_GWIND_X);
   constexpr int NB = PF + 1;               // level buffers
   constexpr int NS = TR + 2;               // row slots per level: slot s holds tile row s - 1
   constexpr int KMAX = (NS + NL - 1) / NL; // row slots per loader wave
@@ -64,7 +92,8 @@ __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 
   const int first = 1 + rblock * TR; // rows 1 .. ny-2 are computed
   const int col = wc * 256 + lane * 4;
   const bool act = col < nx;
-  const int col_c = act ? col : nx - 4;
+  const int col_c = act ? col : (RAGGED ? 0 : nx - 4);
+  const int nvalid = RAGGED ? ((nx - col) < 4 ? (nx - col) : 4) : 4; // cells of this lane's group inside the row (<= 0: none)
   int east_col = wc * 256 + 256;
   if (east_col > nx)
     east_col = nx;
@@ -73,6 +102,9 @@ __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 
     // ------------------------------------------------------------------ loader
     const int lw = wave - TR;
     int off[KMAX], slot_of[KMAX];
+    int off_end[KMAX]; // RAGGED: the same with the group that would reach past the end of the level pulled back inside it
+    bool fix[KMAX];
+    const long last_idx = (long)nx * ny - 1;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       int s = lw + NL * k;
@@ -82,6 +114,8 @@ __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 
       const int j = jr < ny - 1 ? jr : ny - 1; // rows past the field: the last row, never used
       slot_of[k] = s;
       off[k] = j * nx + col_c; // offsets inside a level fit 32 bits (the launcher checks)
+      fix[k] = RAGGED && ((long)off[k] + 3 > last_idx);
+      off_end[k] = fix[k] ? (int)last_idx - 3 : off[k];
     }
     // edge scalars: lane i gathers (slot i / 2, side i % 2); lanes past 2 NS repeat lane 0's
     const int ei = (lane < 2 * NS) ? lane : 0;
@@ -100,13 +134,36 @@ __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 
       auto issue = [&](int lev, int b) {
         const int l = lev < lev1 ? lev : lev1 - 1; // past the chunk: a valid address into a buffer nobody reads
         const float* __restrict__ f = P.f + (size_t)l * P.in_stride;
+        const bool at_end = RAGGED && l == P.nlev - 1; // no next level for a partial group to read into
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(f + off[k]),
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(f + (at_end ? off_end[k] : off[k])),
                                            (void __attribute__((address_space(3)))*)&srow[b][slot_of[k]][0], 16, 0, 0);
         if (EDGE)
           __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(f + eoff), (void __attribute__((address_space(3)))*)&sedge[b][0],
                                            4, 0, 0);
+        if constexpr (RAGGED) {
+          bool mine = false;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            mine = mine | fix[k];
+          if (at_end && __builtin_amdgcn_ballot_w64(mine) != 0) { // one workgroup of the launch, its last level
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pulled-back copy has landed: it is overwritten now
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+              if (fix[k]) {
+                v4f q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  const long i = (long)off[k] + c;
+                  if (i <= last_idx)
+                    q[c] = f[i];
+                }
+                srow[b][slot_of[k]][lane] = q;
+              }
+            }
+          }
+        }
       };
 #pragma unroll
       for (int k = 0; k < PF; ++k)
@@ -163,12 +220,21 @@ __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 
   {
     v4f xm4 = {1.f, 1.f, 1.f, 1.f}, ym4 = xm4, fc4 = xm4;
     if (computes) {
-      if (USE_XM)
-        xm4 = ld4(P.xm + o);
-      if (USE_YM)
-        ym4 = ld4(P.ym + o);
-      if (USE_FC)
-        fc4 = ld4(P.fc + o);
+      if constexpr (RAGGED) { // dword-aligned rows: unaligned 16-byte loads (a partial group reads into the next row, which exists)
+        if (USE_XM)
+          xm4 = reinterpret_cast<const V4Any*>(P.xm + o)->v;
+        if (USE_YM)
+          ym4 = reinterpret_cast<const V4Any*>(P.ym + o)->v;
+        if (USE_FC)
+          fc4 = reinterpret_cast<const V4Any*>(P.fc + o)->v;
+      } else {
+        if (USE_XM)
+          xm4 = ld4(P.xm + o);
+        if (USE_YM)
+          ym4 = ld4(P.ym + o);
+        if (USE_FC)
+          fc4 = ld4(P.fc + o);
+      }
     }
     H.init(xm4, ym4, fc4);
   }
@@ -209,30 +275,62 @@ __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 
         z0[k] = ok ? r0 : undef;
         z1[k] = ok ? r1 : undef;
         if (CHECK)
-          bad += (!ok & act) ? 1u : 0u;
+          bad += (!ok & act & (k < nvalid)) ? 1u : 0u;
       }
       if (col == 0) { // fillEdges, column part (:65-68)
         z0[0] = z0[1];
         z1[0] = z1[1];
       }
-      if (col + 4 == nx) {
+      if constexpr (RAGGED) { // ... for any width: the value of column nx-2 may sit in the lane below
+        const int k_last = nx - 1 - col; // 0 .. 3 in the lane that holds column nx-1
+        const float below0 = dpp_lower(z0[3], z0[3]), below1 = dpp_lower(z1[3], z1[3]); // every lane of the wave is here
+        if (k_last == 0) {
+          z0[0] = below0;
+          z1[0] = below1;
+        } else if (k_last == 1) {
+          z0[1] = z0[0];
+          z1[1] = z1[0];
+        } else if (k_last == 2) {
+          z0[2] = z0[1];
+          z1[2] = z1[1];
+        } else if (k_last == 3) {
+          z0[3] = z0[2];
+          z1[3] = z1[2];
+        }
+      } else if (col + 4 == nx) {
         z0[3] = z0[2];
         z1[3] = z1[2];
       }
       if (act) {
         float* o0p = P.o0 + (size_t)lev * P.out_stride;
-        st4_stream(o0p + oo, z0);
-        if (top) // fillEdges, row part (:70-73)
-          st4_stream(o0p + oo - nx, z0);
-        if (bottom)
-          st4_stream(o0p + oo + nx, z0);
-        if (TWO_OUT) {
-          float* o1p = P.o1 + (size_t)lev * P.out_stride;
-          st4_stream(o1p + oo, z1);
-          if (top)
-            st4_stream(o1p + oo - nx, z1);
+        if constexpr (RAGGED) {
+          st4_any_alignment(o0p + oo, z0, nvalid);
+          if (top) // fillEdges, row part (:70-73)
+            st4_any_alignment(o0p + oo - nx, z0, nvalid);
           if (bottom)
-            st4_stream(o1p + oo + nx, z1);
+            st4_any_alignment(o0p + oo + nx, z0, nvalid);
+          if (TWO_OUT) {
+            float* o1p = P.o1 + (size_t)lev * P.out_stride;
+            st4_any_alignment(o1p + oo, z1, nvalid);
+            if (top)
+              st4_any_alignment(o1p + oo - nx, z1, nvalid);
+            if (bottom)
+              st4_any_alignment(o1p + oo + nx, z1, nvalid);
+          }
+        } else {
+          st4_stream(o0p + oo, z0);
+          if (top) // fillEdges, row part (:70-73)
+            st4_stream(o0p + oo - nx, z0);
+          if (bottom)
+            st4_stream(o0p + oo + nx, z0);
+          if (TWO_OUT) {
+            float* o1p = P.o1 + (size_t)lev * P.out_stride;
+            st4_stream(o1p + oo, z1);
+            if (top)
+              st4_stream(o1p + oo - nx, z1);
+            if (bottom)
+              st4_stream(o1p + oo + nx, z1);
+          }
         }
       }
       if (CHECK && P.n_undefined && !all && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {
@@ -280,7 +378,7 @@ int shape_value(const char* s, const char* key, int dflt)
 //     inputs but d/dy, whose arithmetic phases then overlap (the 14-wave shape runs the tested ones 15-25 % slower;
 //     profiles/r03/split_role_ops_placed.txt has both shapes for every operator on one set of placed arrays).
 // MIFC_SCALAR_SPLIT_TUNE="TR=12,NL=2,PF=2,LG=6" overrides (A/B measurements and tests; only the shapes instantiated below exist).
-SplitShape current_shape(int op, bool check)
+SplitShape current_shape(int op, bool check, bool ragged = false)
 {
   const bool issue_bound = op == ST_GRAD_ABS || op == ST_GRAD_LAP || op == ST_GVORT || (check && op != ST_GRAD_Y);
   SplitShape sh = issue_bound ? SplitShape{14, 2, 2, 0} : SplitShape{12, 2, 3, 0};
@@ -291,6 +389,8 @@ SplitShape current_shape(int op, bool check)
     sh.pf = shape_value(s, "PF", sh.pf);
     sh.lg = shape_value(s, "LG", sh.lg);
   }
+  if (ragged) // the variant for rows at any alignment exists in the two default shapes
+    sh = (sh.tr == 14) ? SplitShape{14, 2, 2, sh.lg} : SplitShape{12, 2, 3, sh.lg};
   return sh;
 }
 
@@ -301,6 +401,23 @@ void launch_shape(const SRowsParams& rp, bool check, int grid, hipStream_t strea
     hipLaunchKernelGGL((scalar_split_kernel<OP, true, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
   else
     hipLaunchKernelGGL((scalar_split_kernel<OP, false, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
+}
+
+// rows at any alignment: the two default shapes only
+template <int OP>
+void launch_ragged(const SRowsParams& rp, const SplitShape& sh, bool check, int grid, hipStream_t stream)
+{
+  if (sh.tr == 14) {
+    if (check)
+      hipLaunchKernelGGL((scalar_split_kernel<OP, true, 14, 2, 2, true>), dim3(grid), dim3(64 * 16), 0, stream, rp);
+    else
+      hipLaunchKernelGGL((scalar_split_kernel<OP, false, 14, 2, 2, true>), dim3(grid), dim3(64 * 16), 0, stream, rp);
+  } else {
+    if (check)
+      hipLaunchKernelGGL((scalar_split_kernel<OP, true, 12, 2, 3, true>), dim3(grid), dim3(64 * 14), 0, stream, rp);
+    else
+      hipLaunchKernelGGL((scalar_split_kernel<OP, false, 12, 2, 3, true>), dim3(grid), dim3(64 * 14), 0, stream, rp);
+  }
 }
 
 // the instantiated shapes: {tile rows, loader waves, levels ahead}
@@ -319,6 +436,10 @@ bool shape_exists(const SplitShape& sh)
 template <int OP>
 void launch_op(const SRowsParams& rp, const SplitShape& sh, bool check, int grid, hipStream_t stream)
 {
+  if (rp.ragged) {
+    launch_ragged<OP>(rp, sh, check, grid, stream);
+    return;
+  }
 #define X(TR_, NL_, PF_) \
   if (sh.tr == TR_ && sh.nl == NL_ && sh.pf == PF_) { \
     launch_shape<OP, TR_, NL_, PF_>(rp, check, grid, stream); \
@@ -344,13 +465,15 @@ bool plan(const SplitShape& sh, int nx, int ny, int nlev, int* levels_per_chunk,
 
 } // namespace
 
-bool scalar_split_applies(int op, int nx, int ny, int nlev, bool check, float undef)
+bool scalar_split_applies(int op, int nx, int ny, int nlev, bool check, float undef, bool ragged)
 {
+  if (ragged && !env().ragged_split)
+    return false;
   if (!env().split_roles || !env().levelwalk || op < ST_GRAD_X || op > ST_IGWIND)
     return false;
   if (check && undef != undef) // the kernel tests with ONE compare per value, which is is_def() only for an undef that is not NaN
     return false;
-  const SplitShape sh = current_shape(op, check);
+  const SplitShape sh = current_shape(op, check, ragged);
   int lpc;
   long units;
   if (!shape_exists(sh) || !plan(sh, nx, ny, nlev, &lpc, &units))
@@ -360,7 +483,7 @@ bool scalar_split_applies(int op, int nx, int ny, int nlev, bool check, float un
 
 hipError_t launch_scalar_split(int op, SRowsParams& rp, bool check, hipStream_t stream)
 {
-  const SplitShape sh = current_shape(op, check);
+  const SplitShape sh = current_shape(op, check, rp.ragged != 0);
   int lpc;
   long units;
   if (!shape_exists(sh) || !plan(sh, rp.nx, rp.ny, rp.nlev, &lpc, &units))

@@ -122,6 +122,30 @@ __device__ __forceinline__ void store4(float* p, const v4f& v)
     *reinterpret_cast<v4f*>(p) = v;
 }
 
+// Rows of a field whose width is not a multiple of 4 start at dword-aligned addresses only.  16-byte stores there run at
+// 75 % of the aligned store rate (profiles/r03/experiments/ragged_probe.txt: 3.8 against 5.0 TB/s; four dword stores per
+// lane writing contiguous 256-byte runs are no better, nontemporal ones worse), loads -- global_load_lds_dwordx4 included --
+// do not care.  A group that reaches over the end of its row stores its valid cells one by one.
+struct __attribute__((packed, aligned(4))) V4Unaligned
+{
+  v4f v;
+};
+__device__ __forceinline__ void store4_any_alignment(float* p, const v4f& v, int nvalid)
+{
+  if (nvalid >= 4) {
+    V4Unaligned t;
+    t.v = v;
+    *reinterpret_cast<V4Unaligned*>(p) = t;
+  } else {
+    if (nvalid > 0)
+      p[0] = v.x;
+    if (nvalid > 1)
+      p[1] = v.y;
+    if (nvalid > 2)
+      p[2] = v.z;
+  }
+}
+
 #ifdef MIFC_MEASUREMENT_BUILD
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 // base: wave-uniform start of the level's output field; off: element offset
@@ -1072,10 +1096,16 @@ chunk_done:;
 // LDS anyway -- BASELINE.json config 5 computes ff next to vorticity and divergence per member, and as a separate launch ff
 // reads u and v a second time (44 -> 36 B per cell for the member).  Rows 0 and ny-1 have no compute wave of their own: the
 // waves of rows 1 and ny-2, which fill them for the stencil outputs, compute their ff from the halo slots.
-template <bool CHECK, bool NT, int TR, int NL, int PF, bool WANT_V = true, bool WANT_D = true, bool ABSV = false, bool FF = false>
+// RAGGED (round 3): any width and dword-aligned fields.  The tiles stay 256 columns wide in COLUMN space, so rows start
+// wherever they start: the loaders do not care (see store4_any_alignment), the stores are 16-byte stores at dword
+// alignment, the last column group of a row may be partial (its trailing cells are the first cells of the next row -- exactly
+// the flat neighbours the reference's loop sees at column nx-1), and the one group whose 16 bytes would reach past the END
+// of the batch (last row of the last level) is loaded cell by cell by its loader.
+template <bool CHECK, bool NT, int TR, int NL, int PF, bool WANT_V = true, bool WANT_D = true, bool ABSV = false, bool FF = false, bool RAGGED = false>
 __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const RowsParams P)
 {
   static_assert(WANT_V || WANT_D, "nothing to compute");
+  static_assert(!(RAGGED && FF), "the three-output form takes aligned fields only");
   static_assert(!FF || (WANT_V && WANT_D && !ABSV), "the wind speed rides on the fused pair");
   static_assert(!ABSV || (WANT_V && !WANT_D), "absvort is a single-output operator");
   constexpr int NB = PF + 1;                // level buffers
@@ -1111,7 +1141,8 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
   const int first = P.lo + rblock * TR; // first row of the tile (always computed)
   const int col = wc * 256 + lane * 4;
   const bool act = col < nx;
-  const int col_c = act ? col : nx - 4;
+  const int col_c = act ? col : (RAGGED ? 0 : nx - 4);
+  const int nvalid = RAGGED ? ((nx - col) < 4 ? (nx - col) : 4) : 4; // cells of this lane's group inside the row (<= 0: none)
   int east_col = wc * 256 + 256;
   if (east_col > nx)
     east_col = nx;
@@ -1120,6 +1151,8 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
     // ------------------------------------------------------------------ loader
     const int lw = wave - TR;
     int off[KMAX], slot_of[KMAX];
+    int off_end[KMAX]; // RAGGED: the same with the groups that would reach past the valid range pulled back inside it
+    bool fix[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       int s = lw + NL * k;
@@ -1129,6 +1162,8 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
       const int jl = jl_raw < P.hi ? jl_raw : P.hi; // rows past the computed range: row `hi` always exists
       slot_of[k] = s;
       off[k] = jl * nx + col_c;
+      fix[k] = RAGGED && ((long)off[k] + 3 > P.idx_hi);
+      off_end[k] = fix[k] ? (int)P.idx_hi - 3 : off[k];
     }
     // edge scalars: lane i gathers (slot i / 4, array (i / 2) % 2, side i % 2); lanes past 4 NS repeat lane 0's
     const int ei = (lane < 4 * NS) ? lane : 0;
@@ -1150,16 +1185,45 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
         const int l = lev < lev1 ? lev : lev1 - 1; // past the chunk: a valid address into a buffer nobody reads
         const float* __restrict__ u = P.u + (size_t)l * P.in_stride;
         const float* __restrict__ v = P.v + (size_t)l * P.in_stride;
+        // behind the last level there is no next level for a partial group to read into: there its 16 bytes are pulled back
+        // inside the batch and the group is loaded again, cell by cell, below
+        const bool at_end = RAGGED && l == P.nlev - 1;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(u + off[k]),
+          const int o = at_end ? off_end[k] : off[k];
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(u + o),
                                            (void __attribute__((address_space(3)))*)&srow[b][slot_of[k]][0][0], 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(v + off[k]),
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(v + o),
                                            (void __attribute__((address_space(3)))*)&srow[b][slot_of[k]][1][0], 16, 0, 0);
         }
         if (EDGE)
           __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(ebase + (size_t)l * P.in_stride + eoff),
                                            (void __attribute__((address_space(3)))*)&sedge[b][0], 4, 0, 0);
+        if constexpr (RAGGED) {
+          bool mine = false;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            mine = mine | fix[k];
+          if (at_end && __builtin_amdgcn_ballot_w64(mine) != 0) { // one workgroup of the launch, its last level
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pulled-back copies have landed: they are overwritten now
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+              if (fix[k]) {
+                v4f qu = {0.f, 0.f, 0.f, 0.f}, qv = qu;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  const long i = (long)off[k] + c;
+                  if (i <= P.idx_hi) {
+                    qu[c] = u[i];
+                    qv[c] = v[i];
+                  }
+                }
+                srow[b][slot_of[k]][0][lane] = qu;
+                srow[b][slot_of[k]][1][lane] = qv;
+              }
+            }
+          }
+        }
       };
 #pragma unroll
       for (int k = 0; k < PF; ++k)
@@ -1223,11 +1287,61 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
   const int oo = base + col;
   v4f xm4 = {0.f, 0.f, 0.f, 0.f}, ym4 = xm4, fc4 = xm4;
   if (computes) { // the tile's map factors: once, for every level of the chunk
-    xm4 = load4(P.xm + o);
-    ym4 = load4(P.ym + o);
-    if constexpr (ABSV)
-      fc4 = load4(P.fc + o);
+    if constexpr (RAGGED) { // (dword-aligned rows: unaligned 16-byte loads; a partial group reads into the next row, which exists)
+      xm4 = reinterpret_cast<const V4Unaligned*>(P.xm + o)->v;
+      ym4 = reinterpret_cast<const V4Unaligned*>(P.ym + o)->v;
+      if constexpr (ABSV)
+        fc4 = reinterpret_cast<const V4Unaligned*>(P.fc + o)->v;
+    } else {
+      xm4 = load4(P.xm + o);
+      ym4 = load4(P.ym + o);
+      if constexpr (ABSV)
+        fc4 = load4(P.fc + o);
+    }
   }
+  // fillEdges, column part (:65-68), for any width: the last column takes the value of the one before it, which may sit in
+  // the lane below (the group that holds column nx-1 then holds nothing else)
+  const int k_last = nx - 1 - col; // 0 .. 3 in the lane that holds column nx-1
+  auto fill_columns = [&](float (&z)[4]) __attribute__((always_inline)) {
+    if (col == 0)
+      z[0] = z[1];
+    if constexpr (RAGGED) {
+      const float below = dpp_from_lower_lane(z[3], z[3]); // every lane of the wave is here
+      if (k_last == 0)
+        z[0] = below;
+      else if (k_last == 1)
+        z[1] = z[0];
+      else if (k_last == 2)
+        z[2] = z[1];
+      else if (k_last == 3)
+        z[3] = z[2];
+    } else {
+      if (col + 4 == nx)
+        z[3] = z[2];
+    }
+  };
+  auto store_rows = [&](float* field, const float (&z)[4]) __attribute__((always_inline)) {
+    if (act) {
+      v4f z4;
+      z4.x = z[0];
+      z4.y = z[1];
+      z4.z = z[2];
+      z4.w = z[3];
+      if constexpr (RAGGED) {
+        store4_any_alignment(field + oo, z4, nvalid);
+        if (top) // fillEdges, row part (:70-73)
+          store4_any_alignment(field + oo - nx, z4, nvalid);
+        if (bottom)
+          store4_any_alignment(field + oo + nx, z4, nvalid);
+      } else {
+        store4<NT>(field + oo, z4);
+        if (top) // fillEdges, row part (:70-73)
+          store4<NT>(field + oo - nx, z4);
+        if (bottom)
+          store4<NT>(field + oo + nx, z4);
+      }
+    }
+  };
   int buf = 0;
   for (int lev = lev0; lev < lev1; ++lev) {
     // the LDS reads of the previous level are consumed (their values went into the stores); stores stay in flight.  The
@@ -1274,26 +1388,11 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
             zv[k] = ok[k] ? z : undef;
           }
           if (CHECK)
-            bad += (!ok[k] & act) ? 1u : 0u;
+            bad += (!ok[k] & act & (k < nvalid)) ? 1u : 0u;
         }
         if constexpr (WANT_V) {
-          if (col == 0) // fillEdges, column part (:65-68)
-            zv[0] = zv[1];
-          if (col + 4 == nx)
-            zv[3] = zv[2];
-          if (act) {
-            float* rv = P.rv + (size_t)lev * P.out_stride;
-            v4f z4;
-            z4.x = zv[0];
-            z4.y = zv[1];
-            z4.z = zv[2];
-            z4.w = zv[3];
-            store4<NT>(rv + oo, z4);
-            if (top) // fillEdges, row part (:70-73)
-              store4<NT>(rv + oo - nx, z4);
-            if (bottom)
-              store4<NT>(rv + oo + nx, z4);
-          }
+          fill_columns(zv);
+          store_rows(P.rv + (size_t)lev * P.out_stride, zv);
         }
       }
       if constexpr (WANT_D) {
@@ -1305,23 +1404,8 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
           const float d = f_diverg(xm4[k], ym4[k], ucx[k + 2] - ucx[k], vn[k] - vs[k]);
           zd[k] = ok[k] ? d : undef;
         }
-        if (col == 0)
-          zd[0] = zd[1];
-        if (col + 4 == nx)
-          zd[3] = zd[2];
-        if (act) {
-          float* dv = P.dv + (size_t)lev * P.out_stride;
-          v4f d4;
-          d4.x = zd[0];
-          d4.y = zd[1];
-          d4.z = zd[2];
-          d4.w = zd[3];
-          store4<NT>(dv + oo, d4);
-          if (top)
-            store4<NT>(dv + oo - nx, d4);
-          if (bottom)
-            store4<NT>(dv + oo + nx, d4);
-        }
+        fill_columns(zd);
+        store_rows(P.dv + (size_t)lev * P.out_stride, zd);
       }
       if (CHECK && P.n_undefined && !all && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {
         const unsigned int n = wave_sum(bad);
@@ -1544,7 +1628,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     dv = prm.out0;
   } else if (prm.op == ST_ABSVORT) {
     rv = prm.out0;
-    if (!prm.fcoriolis || !aligned16(prm.fcoriolis))
+    if (!prm.fcoriolis)
       return hipSuccess;
   } else if (prm.op == ST_JACOBIAN) {
     rv = prm.out0;
@@ -1554,11 +1638,16 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   if (!rv && !dv)
     return hipSuccess;
   const int nx = prm.nx;
-  if (nx % 4 != 0 || nx < 8 || prm.ny_global < 3)
+  if (nx < 8 || prm.ny_global < 3)
     return hipSuccess;
-  if (!aligned16(prm.f0) || !aligned16(prm.f1) || !aligned16(prm.xmapr) || !aligned16(prm.ymapr) || (rv && !aligned16(rv)) || (dv && !aligned16(dv)))
-    return hipSuccess;
-  if (prm.in_level_stride % 4 != 0 || prm.out_level_stride % 4 != 0)
+  // Rows that do not start at 16-byte boundaries (a width that is not a multiple of 4, unaligned fields or level strides): only
+  // the split-role kernel has a form for them (RAGGED, round 3), i.e. deep batches of the wind operators; everything else is
+  // left to the flat four-cells-per-lane kernel
+  const bool ragged = nx % 4 != 0 || !aligned16(prm.f0) || !aligned16(prm.f1) || !aligned16(prm.xmapr) || !aligned16(prm.ymapr) || (rv && !aligned16(rv)) ||
+                      (dv && !aligned16(dv)) || prm.in_level_stride % 4 != 0 || prm.out_level_stride % 4 != 0 ||
+                      (prm.op == ST_ABSVORT && prm.fcoriolis && !aligned16(prm.fcoriolis));
+  // (nx % 256 == 1: the column whose value fillEdges copies into column nx-1 belongs to another workgroup)
+  if (ragged && (nx % 256 == 1 || prm.op == ST_JACOBIAN || env().has_vortdiv_tune || !env().split_roles || !env().levelwalk || !env().ragged_split || prm.out_ff))
     return hipSuccess;
   if (env().force_cell_kernel)
     return hipSuccess;
@@ -1579,7 +1668,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     // bands put more waves on the chip, and their halo re-reads stay in L2.
     // One 1440x720 level: 8-row bands 270 waves, 2-row bands 1077; 8 levels (a chunk of the host pipeline) keep 8.
     const long rows = prm.ny_local, wcols = (nx + 256 * t.V - 1) / (256 * t.V), waves_per_band = (long)prm.nlev * wcols;
-    const bool small = waves_per_band * ((rows + t.R - 1) / t.R) < 2048;
+    // (MIFC_LEVELWALK_MIN_UNITS, the tests' switch, sends launches of any size to the level-walking forms)
+    const bool small = env().levelwalk_min_units <= 0 && waves_per_band * ((rows + t.R - 1) / t.R) < 2048;
     if (small || prm.nlev <= 2) {
       // ... and the wind operators have forms without any row loop.  Small launches: one 1440x720 level takes
       // 6.7 us (7.5 us with tests and counts) instead of 7.3 (10.8) with 2-row bands, 12.9 (21.6) with 8-row
@@ -1610,7 +1700,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         // kernel it ran before, which has no level-walking form of the first kind); relvort / divergence ALONE measure
         // the same in both forms (12 B per cell: +-1 %, the sign depends on the box -- profiles/r03/split_role_ops.txt) and
         // keep the first, MIFC_VORTDIV_TUNE="K=4,..." selects the split-role one.
-        if (env().split_roles && !nan_undef_tested && ((rv && dv) || prm.op == ST_ABSVORT)) {
+        if (env().split_roles && !nan_undef_tested && ((rv && dv) || prm.op == ST_ABSVORT || ragged)) {
           t.K = 4;
           t.D = 1;
           t.WPB = 2;
@@ -1682,8 +1772,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.n_undefined = prm.n_undefined;
   int grid = rp.per_xcd * 8;
 
-  if (prm.out_ff && t.K != 4)
-    return hipSuccess; // (see above: only the split-role kernel has the third output)
+  if ((prm.out_ff || ragged) && t.K != 4)
+    return hipSuccess; // (see above: only the split-role kernel has the third output / takes rows at any alignment)
   *handled = true;
   if ((t.K == 1 || t.K == 2) && rp.fc) { // one-shot forms of absvort (relvort + the Coriolis parameter)
     const bool tiles = t.K == 2;
@@ -1843,7 +1933,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   }
   if (t.K == 4 && prm.op != ST_JACOBIAN) { // split-role level-walking tiles (loader waves / compute waves)
     const bool single = !(rv && dv) || rp.fc; // one output: the default shape only (and its one-level-ahead sibling)
-    const int tile_rows = single ? 12 : ((t.RB == 6 || t.RB == 8 || t.RB == 12 || t.RB == 14) ? t.RB : 10);
+    const int tile_rows = (single || ragged || prm.out_ff) ? 12 : ((t.RB == 6 || t.RB == 8 || t.RB == 12 || t.RB == 14) ? t.RB : 10);
     const int nchunks_lg = (t.LG > 0 && t.LG < prm.nlev) ? t.LG : prm.nlev; // levels per workgroup
     const int nchunks = (prm.nlev + nchunks_lg - 1) / nchunks_lg;
     const long units = (long)nchunks * ((rp.hi - rp.lo + tile_rows - 1) / tile_rows) * ((nx + 255) / 256);
@@ -1867,6 +1957,18 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     hipLaunchKernelGGL((vortdiv_split_kernel<false, true, TR_, NL_, PF_, ##__VA_ARGS__>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp)
     if (prm.out_ff) { // the fused pair plus the wind speed: the default shape
       SPLIT_AS(12, 2, 2, true, true, false, true);
+      return hipGetLastError();
+    }
+    if (ragged) { // rows at any alignment: the default shape
+      if (rp.fc) {
+        SPLIT_AS(12, 2, 2, true, false, true, false, true);
+      } else if (rv && dv) {
+        SPLIT_AS(12, 2, 2, true, true, false, false, true);
+      } else if (rv) {
+        SPLIT_AS(12, 2, 2, true, false, false, false, true);
+      } else {
+        SPLIT_AS(12, 2, 2, false, true, false, false, true);
+      }
       return hipGetLastError();
     }
     if (single) {

@@ -713,6 +713,84 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc
             assert fo[l] == f_e, (name, l, fo[l], f_e)
 
 
+@pytest.mark.parametrize("nx,ny,nlev,shift", [(949, 23, 4, 0), (1001, 27, 3, 0), (258, 15, 5, 0), (1443, 16, 3, 0), (515, 14, 7, 0), (1442, 26, 3, 0), (257, 9, 3, 0),
+                                               (516, 25, 4, 1), (1440, 15, 3, 3), (260, 38, 3, 2)])
+@pytest.mark.parametrize("ragged_split", ["1", "0"])
+def test_split_role_kernels_on_rows_at_any_alignment(gpu_ctx, oracle, nx, ny, nlev, shift, ragged_split, mifc_env):
+    """The RAGGED variants of the split-role level-walking kernels (mifc_vortdiv.hip, mifc_stencil_split.hip): widths that are
+    not a multiple of 4 (the last column group of a row is partial: remainders 1, 2 and 3, the fill column in the lane below
+    and in the own lane), and widths that are but with every field `shift` floats off the 16-byte grid (views into larger
+    arrays).  Each operator over a batch == the per-level reference call, flags included; the batch ends where its
+    allocation ends, so the last group of the last level is the one loaded cell by cell.  257 (one column in the last segment)
+    is declined and takes the flat kernels, as everything does under MIFC_RAGGED_SPLIT=0."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    mifc_env("MIFC_LEVELWALK_MIN_UNITS", "1")
+    mifc_env("MIFC_RAGGED_SPLIT", ragged_split)
+    xm, ym, fcor = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 4242 + nx, nlev=nlev)
+    z = np.stack([synth.scalar_field(nx, ny, 4300 + l) for l in range(nlev)])
+    flags = np.full(nlev, SOME, np.int32)
+    flags[0] = ALL
+    for l in range(1, nlev):
+        if l % 2:
+            u[l] = synth.sprinkle_undef(u[l], 10 + l, 0.03)
+            z[l] = synth.sprinkle_undef(z[l], 20 + l, 0.03)
+    # undefined values where the partial group and the fill columns are: last columns of rows 1 and ny-2, first column
+    u[nlev - 1, 1, nx - 2] = cases.UNDEF
+    z[nlev - 1, ny - 2, nx - 1] = cases.UNDEF
+    z[nlev - 1, ny - 1, nx - 1] = cases.UNDEF
+    z[nlev - 1, 2, 0] = cases.UNDEF
+
+    def dev(a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a)
+        big = torch.empty(a.size + shift, dtype=torch.float32, device="cuda")
+        t = big[shift:].view(a.shape)
+        t.copy_(torch.from_numpy(a))
+        assert t.data_ptr() % 16 == 4 * shift
+        return t
+
+    dxm, dym, dfc = dev(xm), dev(ym), dev(fcor)
+    def table_of(u, v, z):
+        return [("vortdiv", None, u, v, False, None), ("relvort", "relvort", u, v, False, None), ("divergence", "divergence", u, v, False, None),
+                ("absvort", "absvort", u, v, True, None), ("gradient1", "gradient", z, None, False, 1), ("gradient2", "gradient", z, None, False, 2),
+                ("gradient3", "gradient", z, None, False, 3), ("gradient4", "gradient", z, None, False, 4),
+                ("plevelgwind_xcomp", "plevelgwind_xcomp", z, None, True, None), ("plevelgwind_ycomp", "plevelgwind_ycomp", z, None, True, None),
+                ("plevelgvort", "plevelgvort", z, None, True, None), ("ilevelgwind", "ilevelgwind", z, None, True, None)]
+
+    for all_defined in (False, True):
+        fl = flags
+        if all_defined:  # the variants without tests: clean data, every level ALL_DEFINED
+            fl = np.full(nlev, ALL, np.int32)
+            u, v = synth.wind(nx, ny, 5252 + nx, nlev=nlev)
+            z = np.stack([synth.scalar_field(nx, ny, 5300 + l) for l in range(nlev)])
+        table = table_of(u, v, z)
+        for name, cpu_op, f0, f1, use_fc, compute in table:
+            o0 = dev(np.zeros_like(f0))
+            o1 = dev(np.zeros_like(f0)) if name in ("vortdiv", "ilevelgwind") else None
+            res = gpu_ctx.stencil_levels(name, dev(f0), dev(f1), dxm, dym, dfc if use_fc else None, fdefined=fl, out0=o0, out1=o1)
+            assert res is not None, name
+            (r0, r1), fo = res
+            r0 = r0.cpu().numpy()
+            r1 = None if r1 is None else r1.cpu().numpy()
+            for l in range(nlev):
+                if name == "vortdiv":
+                    ok, e0, f_e = oracle.call("relvort", nx, ny, f0[l], f1[l], xm, ym, fdefined=int(fl[l]))
+                    ok, e1, _ = oracle.call("divergence", nx, ny, f0[l], f1[l], xm, ym, fdefined=int(fl[l]))
+                else:
+                    args = [f0[l]] + ([f1[l]] if f1 is not None else []) + [xm, ym] + ([fcor] if use_fc else []) + ([compute] if compute else [])
+                    ok, e, f_e = oracle.call(cpu_op, nx, ny, *args, fdefined=int(fl[l]))
+                    e0, e1 = (e if isinstance(e, tuple) else (e, None))
+                assert cases.same_bits(r0[l], e0, nan_payload=False), (name, l, all_defined)
+                if e1 is not None:
+                    assert cases.same_bits(r1[l], e1, nan_payload=False), (name, l, all_defined)
+                assert fo[l] == f_e, (name, l, fo[l], f_e)
+
+
 @pytest.mark.parametrize("nx,ny,nlev,walk", [(516, 70, 6, "1"), (1440, 40, 9, "1"), (260, 11, 5, "1"), (64, 48, 2, None), (949, 23, 4, "1"), (1440, 75, 5, None)])
 def test_vortdiv_ff_levels_three_outputs_in_one_pass(gpu_ctx, oracle, nx, ny, nlev, walk, mifc_env):
     """mifc_vortdiv_ff_levels_enqueue: relvort, divergence and vectorabs of every level == the three reference calls bit for
