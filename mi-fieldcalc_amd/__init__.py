@@ -671,6 +671,10 @@ class Context:
                                                         None if n_undefined is None else n_undefined.data_ptr()])
         return bool(rc)
 
+    def last_stencil_form(self):
+        """The kernel form this thread's last stencil launch took (mifc_last_stencil_form; a diagnostic for tests)."""
+        return self._lib.mifc_last_stencil_form().decode()
+
     def stencil_count_domain(self, op, nx, ny):
         return int(self._lib.mifc_stencil_count_domain(self.OPS[op], nx, ny))
 

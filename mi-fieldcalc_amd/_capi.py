@@ -128,6 +128,7 @@ SIGNATURES = {
     "mifc_vortdiv_ff_levels_enqueue": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "pu", "pu"]),
     "mifc_stencil_levels_enqueue": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "pi", "f", "pu"]),
     "mifc_stencil_count_domain": ("u64", ["i", "i", "i"]),
+    "mifc_last_stencil_form": ("s", []),
     "mifc_stencil_levels_ex": ("i", ["ctx", "i", "i", "i", "i", "p", "p", "p", "p", "p", "p", "p", "f", "i", "p", "p", "pi", "f", "i"]),
     "mifc_vortdiv_levels_enqueue": ("i", ["ctx", "i", "i", "i", "p", "p", "p", "p", "p", "p", "pi", "f", "pu"]),
     "mifc_batch_level_stride": ("z", ["i", "i"]),

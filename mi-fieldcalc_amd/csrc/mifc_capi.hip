@@ -1671,6 +1671,11 @@ int mifc_vortdiv_ff_levels_enqueue(mifc_ctx* c, int nx, int ny, int nlev, const 
   return 1;
 }
 
+const char* mifc_last_stencil_form(void)
+{
+  return mifc::last_form();
+}
+
 unsigned long long mifc_stencil_count_domain(int op, int nx, int ny)
 {
   return stencil_denominator(op, nx, ny);

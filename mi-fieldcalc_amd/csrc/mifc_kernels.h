@@ -263,6 +263,10 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream);
 // kernel arguments and are expanded into d_flags (u8[nlev], null: none needed), d_counts[0 .. n_counts) is zeroed
 // (null: nothing to zero).  Returns hipErrorInvalidValue beyond kPrepMaxLevels levels (the caller then copies and fills).
 constexpr int kPrepMaxLevels = 2048;
+// Which kernel form the calling thread's last stencil launch took ("wind_split", "scalar_oneshot", "flat4" ...): a
+// diagnostic for tests and bug reports (mifc_last_stencil_form), nothing reads it on the data path.
+void note_form(const char* form);
+const char* last_form();
 hipError_t launch_prep_levels(const unsigned char* host_flags, int nlev, unsigned char* d_flags, u64* d_counts, int n_counts, hipStream_t stream);
 
 // second-order Shapiro filter, FieldCalculations.cc:2076 (mifc_shapiro.hip)

@@ -619,10 +619,23 @@ hipError_t launch_prep_levels(const unsigned char* host_flags, int nlev, unsigne
   return hipGetLastError();
 }
 
+namespace {
+thread_local const char* t_last_form = "";
+}
+void note_form(const char* form)
+{
+  t_last_form = form;
+}
+const char* last_form()
+{
+  return t_last_form;
+}
+
 hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
 {
   if (prm.nlev <= 0)
     return hipSuccess;
+  note_form("");
   if (prm.op == ST_VORTDIV || prm.op == ST_RELVORT || prm.op == ST_DIVERGENCE || prm.op == ST_ABSVORT || prm.op == ST_JACOBIAN) {
     bool handled = false;
     const hipError_t e = launch_vortdiv_rows(prm, stream, &handled);
@@ -642,6 +655,10 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
     const hipError_t e = launch_advection_oneshot(prm, stream, &handled);
     if (handled)
       return e;
+  }
+  {
+    const bool cell_only = prm.op == ST_GRAD_X || prm.op == ST_ADVECTION || prm.op == ST_TFP || prm.op == ST_QVEC_X || prm.op == ST_QVEC_Y;
+    note_form(!cell_only && wind_flat4_applies(prm) ? "flat4" : "cell");
   }
   switch (prm.op) {
   case ST_RELVORT:

@@ -564,6 +564,7 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
       rp.n_undefined = prm.n_undefined;
       rp.ragged = 1;
       *handled = true;
+      note_form("scalar_split_ragged");
       const hipError_t e = launch_scalar_split(op, rp, check, stream);
       if (e == hipSuccess && op == ST_GRAD_X && check && rp.n_undefined) {
         for (int l0 = 0; l0 < prm.nlev; l0 += 65535) { // grid.y limit; see count_outer_rows below
@@ -692,7 +693,9 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   };
   // Deep batches, round 3: the level-walking tiles with split roles (mifc_stencil_split.hip) -- loader waves fill LDS two
   // levels ahead, compute waves only read LDS and store, two workgroups per CU -- for every operator of the family.
+  note_form(form == 0 ? "scalar_oneshot" : form == 3 ? "scalar_levelwalk" : "scalar_rows");
   if (form != 0 && forced_r < 0 && scalar_split_applies(op, nx, ny, prm.nlev, check, prm.undef, false)) {
+    note_form("scalar_split");
     const hipError_t e = launch_scalar_split(op, rp, check, stream);
     if (e == hipSuccess && op == ST_GRAD_X)
       count_outer_rows();

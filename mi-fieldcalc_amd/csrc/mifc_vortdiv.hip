@@ -1775,6 +1775,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   if ((prm.out_ff || ragged) && t.K != 4)
     return hipSuccess; // (see above: only the split-role kernel has the third output / takes rows at any alignment)
   *handled = true;
+  note_form(t.K == 1 ? "wind_oneshot" : t.K == 2 ? "wind_oneshot_tiles" : t.K == 3 ? "wind_levelwalk"
+            : t.K == 4 ? (ragged ? "wind_split_ragged" : prm.out_ff ? "wind_split_ff" : "wind_split") : "wind_rows");
   if ((t.K == 1 || t.K == 2) && rp.fc) { // one-shot forms of absvort (relvort + the Coriolis parameter)
     const bool tiles = t.K == 2;
     rp.uB = (rp.hi - rp.lo + (tiles ? 7 : 3)) / (tiles ? 8 : 4);

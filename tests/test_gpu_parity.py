@@ -665,9 +665,11 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc
 
     import mi_fieldcalc_amd.synth as synth
 
+    nosplit = False
     if walk is not None and "/" in walk:
         walk, how = walk.split("/")
         if how == "nosplit":
+            nosplit = True
             mifc_env("MIFC_VORTDIV_SPLIT", "0")
         else:
             mifc_env("MIFC_SCALAR_SPLIT_TUNE", how)
@@ -697,6 +699,15 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc
     for name, cpu_op, f0, f1, use_fc, compute, _ in table:
         res = gpu_ctx.stencil_levels(name, dev(f0), dev(f1), dxm, dym, dfc if use_fc else None, fdefined=flags)
         assert res is not None, name
+        if on_device:  # the case reaches the kernel it is meant for
+            if name == "jacobian":
+                want_form = "wind_rows"
+            elif f1 is not None:
+                split = not nosplit and name in ("vortdiv", "absvort")
+                want_form = "wind_split" if split else ("wind_rows" if name == "absvort" else "wind_levelwalk")
+            else:
+                want_form = "scalar_levelwalk" if nosplit else "scalar_split"
+            assert gpu_ctx.last_stencil_form() == want_form, (name, gpu_ctx.last_stencil_form(), want_form)
         (o0, o1), fo = res
         o0, o1 = host(o0), host(o1)
         for l in range(nlev):
@@ -774,6 +785,10 @@ def test_split_role_kernels_on_rows_at_any_alignment(gpu_ctx, oracle, nx, ny, nl
             o1 = dev(np.zeros_like(f0)) if name in ("vortdiv", "ilevelgwind") else None
             res = gpu_ctx.stencil_levels(name, dev(f0), dev(f1), dxm, dym, dfc if use_fc else None, fdefined=fl, out0=o0, out1=o1)
             assert res is not None, name
+            if ragged_split == "1" and nx % 256 != 1:
+                assert gpu_ctx.last_stencil_form() == ("wind_split_ragged" if f1 is not None else "scalar_split_ragged"), name
+            else:
+                assert gpu_ctx.last_stencil_form() == ("cell" if name == "gradient1" else "flat4"), name
             (r0, r1), fo = res
             r0 = r0.cpu().numpy()
             r1 = None if r1 is None else r1.cpu().numpy()
@@ -811,6 +826,10 @@ def test_vortdiv_ff_levels_three_outputs_in_one_pass(gpu_ctx, oracle, nx, ny, nl
     cnt = torch.full((nlev,), 99, dtype=torch.int64, device="cuda")
     cnt_ff = torch.full((nlev,), 99, dtype=torch.int64, device="cuda")
     assert gpu_ctx.vortdiv_ff_levels_enqueue(du, dvv, dxm, dym, rv, dg, ff, fdefined=flags, n_undefined=cnt, n_undefined_ff=cnt_ff)
+    if walk == "1" and nx % 4 == 0:
+        assert gpu_ctx.last_stencil_form() == "wind_split_ff"
+    else:
+        assert gpu_ctx.last_stencil_form() != "wind_split_ff"
     torch.cuda.synchronize()
     assert cases.same_bits(rv.cpu().numpy(), rv_e, nan_payload=False) and cases.same_bits(dg.cpu().numpy(), dv_e, nan_payload=False)
     c, cf = cnt.cpu().numpy(), cnt_ff.cpu().numpy()
