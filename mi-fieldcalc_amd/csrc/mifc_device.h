@@ -29,11 +29,14 @@ typedef unsigned long long u64;
 #define MIFC_K_RHMIN ((float)0.02)
 #define MIFC_K_RHMAX 1.0f
 #define MIFC_N_EWT 41
-// LDS copy of the table: the 41 values, then 26 start indices for the inverse lookup (one per
-// binary exponent of the argument, see Ewt::inverse)
+// LDS copy of the table: the 41 values, four times +infinity (the inverse lookup's compares read up to four entries past
+// its start index without a range check), then 26 start indices for the inverse lookup (one per binary exponent of the
+// argument, see Ewt::inverse)
+#define MIFC_EWT_PAD 4
+#define MIFC_EWT_FIRST_AT (MIFC_N_EWT + MIFC_EWT_PAD)
 #define MIFC_EWT_FIRST_N 26
-// floats of LDS: ewt[41], first[26], one pad, then 41 doubles: 1 / (ewt[k+1] - ewt[k]) (the table must be 8-byte aligned)
-#define MIFC_EWT_RCP_AT (MIFC_N_EWT + MIFC_EWT_FIRST_N + 1)
+// floats of LDS: ewt[41], +inf[4], first[26], one pad, then 41 doubles: 1 / (ewt[k+1] - ewt[k]) (the table must be 8-byte aligned)
+#define MIFC_EWT_RCP_AT (MIFC_EWT_FIRST_AT + MIFC_EWT_FIRST_N + 1)
 #define MIFC_EWT_LDS (MIFC_EWT_RCP_AT + 2 * MIFC_N_EWT)
 
 // FieldCalculations.h:42-45
@@ -80,19 +83,19 @@ __device__ __forceinline__ void ewt_table_init(float* lds_tab, bool sync = true)
 struct Ewt
 {
   float x;
-  int l;
-  int lc; // l brought into the table: what the lookups index with, so that they need no branch around them --
+  int lc; // int(x) brought into the table: what the lookups index with, so that they need no branch around them --
           // every point function below computes unconditionally and reports ok(); a caller discards the value of
-          // a cell that is not ok (the reference: cell := undef, n_undefined += 1).  lc == l whenever ok().
+          // a cell that is not ok (the reference: cell := undef, n_undefined += 1).  lc == int(x) whenever ok().
   __device__ __forceinline__ explicit Ewt(float t_celsius)
   {
     x = (float)(((double)t_celsius + 100.) * 0.2); // MetConstants.h:65
-    // int(x): the compiled reference (x86-64 cvttss2si) yields INT_MIN for NaN
-    // and out-of-range values; v_cvt_i32_f32 would give 0 / saturate.
-    l = (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : (int)0x80000000;
-    lc = l < 0 ? 0 : (l > MIFC_N_EWT - 2 ? MIFC_N_EWT - 2 : l);
+    // l = int(x), MetConstants.h:66; the compiled reference (x86-64 cvttss2si) yields INT_MIN for NaN and out-of-range
+    // values, i.e. "not in the table" like any other l outside 0 .. 39.  Truncation toward zero: l >= 0 <=> x > -1,
+    // l < 40 <=> x < 40, and neither holds for NaN -- ok() needs no integer; the index is taken from x clamped to the
+    // table (NaN: v_med3_f32 returns the smallest operand, 0).
+    lc = (int)__builtin_amdgcn_fmed3f(x, 0.f, (float)(MIFC_N_EWT - 2));
   }
-  __device__ __forceinline__ bool ok() const { return l >= 0 && l < MIFC_N_EWT - 1; }
+  __device__ __forceinline__ bool ok() const { return x > -1.f && x < (float)(MIFC_N_EWT - 1); }
   __device__ __forceinline__ float value(const float* tab) const { return tab[lc] + (tab[lc + 1] - tab[lc]) * (x - (float)lc); }
   // MetConstants.cc:37-45: `ll = l; while (ll > 0 && ll < 40 && ewt[ll] > et) ll--;` -- a walk
   // down the (strictly increasing) table whose length differs from lane to lane.  The same ll
@@ -112,16 +115,16 @@ struct Ewt
     int b = e < -15 ? 0 : (e > 10 ? 25 : e + 15);
     if (bits < 0)
       b = 0; // negative: no entry satisfies the predicate, the compares below all fail
-    const int m0 = __float_as_int(tab[MIFC_N_EWT + b]);
+    const int m0 = __float_as_int(tab[MIFC_EWT_FIRST_AT + b]);
+    // ewt[m0 + 1 .. m0 + 4]: four reads at constant offsets from one address; past the table they find +infinity, which
+    // is `> et` for every finite et.  (et = +inf or NaN may count up to m0 + 4 = 44: any m above lc means "stay at lc".)
+    const float* at = tab + m0;
     int m = m0;
 #pragma unroll
-    for (int j = 1; j <= 4; ++j) {
-      const int k = m0 + j;
-      const float tk = tab[k < MIFC_N_EWT ? k : MIFC_N_EWT - 1];
-      m += (k < MIFC_N_EWT && !(tk > et)) ? 1 : 0;
-    }
+    for (int j = 1; j <= MIFC_EWT_PAD; ++j)
+      m += !(at[j] > et) ? 1 : 0;
     if (et != et)
-      m = MIFC_N_EWT - 1;
+      m = MIFC_N_EWT - 1; // a NaN with the sign bit set started from 0
     const int ll = m < lc ? m : lc;
 #endif
     // (et - ewt[ll]) / (ewt[ll+1] - ewt[ll]): a quotient of two floats is never closer than 2^-49 (relative) to a
@@ -284,7 +287,10 @@ __device__ __forceinline__ double exp2_tab(const PowTables& T, double t)
 // x^kappa in double for the bits of a float in [2^-32, 2^32)
 __device__ __forceinline__ double pow_kappa_core(const PowTables& T, int ix)
 {
-  const int e = (ix >> 23) - 127;
+  // exponent index e - EMIN = biased exponent - (127 + EMIN); masked into the table so that bits outside the domain (whose
+  // result the callers replace) read some entry of it instead of memory beside it
+  static_assert(MIFC_KAPPA_NE == 64, "the exponent index is masked with 63");
+  const int ei = (((ix >> 23) & 0xff) - (127 + MIFC_KAPPA_EMIN)) & (MIFC_KAPPA_NE - 1);
   const int i = (ix >> 15) & 0xff;
   const double m = (double)__int_as_float((ix & 0x007fffff) | 0x3f800000);
   const double r = fma(m, T.kit[2 * i], -1.0);
@@ -292,7 +298,7 @@ __device__ __forceinline__ double pow_kappa_core(const PowTables& T, int ix)
   p = fma(p, r, MIFC_KAPPA_K2);
   p = fma(p, r, MIFC_KAPPA_K1);
   p = fma(p, r, 1.0);
-  return T.ket[e - MIFC_KAPPA_EMIN] * T.kit[2 * i + 1] * p;
+  return T.ket[ei] * T.kit[2 * i + 1] * p;
 }
 // The arguments outside [2^-32, 2^32) -- no pressure is; what reaches here are undefined cells a tested kernel
 // computes and discards -- inline and without a function call: a call inside a kernel's main loop makes the
@@ -328,8 +334,10 @@ __device__ __forceinline__ float pow_kappa_rare(const PowTables& T, float x)
 }
 __device__ __forceinline__ float pow_kappa(const PowTables& T, float x)
 {
-  const bool fast = x >= 2.3283064365386963e-10f /* 2^-32 */ && x < 4294967296.0f /* 2^32 */;
-  float out = (float)pow_kappa_core(T, __float_as_int(fast ? x : 1.f)); // unconditional: the table reads stay in range
+  // 2^-32 <= x < 2^32 on the bits: one subtraction and one unsigned compare (negative, NaN and infinite x fail it too)
+  const int ix = __float_as_int(x);
+  const bool fast = (unsigned)(ix - 0x2f800000) < 0x20000000u;
+  float out = (float)pow_kappa_core(T, ix); // unconditional: the core keeps its table reads in range for any bits
   if (__builtin_expect(!fast, 0))
     out = pow_kappa_rare(T, x);
   return out;

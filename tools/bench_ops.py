@@ -149,7 +149,7 @@ def main():
             return
         ms, kms = gpu_time(gpu_fn)
         alg = cells * bytes_per_cell + once_bytes
-        cr = cpu_rate(cpu, cpu_op, cpu_args)
+        cr = 0.0 if os.environ.get("BENCH_OPS_NO_CPU") else cpu_rate(cpu, cpu_op, cpu_args)  # A/B runs of two library builds skip the CPU column
         rec = {"op": name, "ms": round(ms, 4), "kernel_ms": round(kms, 4), "Mcells_per_s": round(cells / ms / 1e3, 1), "algorithmic_bytes": alg,
                "GBps": round(alg / ms / 1e6, 1), "frac_of_8TBps": round(alg / ms / 1e6 / PEAK, 4),
                "kernel_frac_of_8TBps": round(alg / kms / 1e6 / PEAK, 4) if kms > 0 else None,
