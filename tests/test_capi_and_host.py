@@ -461,7 +461,9 @@ def test_saturation_table_image_is_current():
     words, first = g.image()
     tab = np.array(words[:41], dtype=np.uint32).view(np.float32)
     assert tab[0] == np.float32(.000034) and tab[40] == np.float32(1013.25)
-    rcp = np.array(words[68:], dtype=np.uint32).view(np.float64)
+    assert all(w == 0x7f800000 for w in words[41:41 + g.N_PAD])  # +inf behind the table: the inverse lookup reads past it unchecked
+    assert words[41 + g.N_PAD:41 + g.N_PAD + g.N_FIRST] == first
+    rcp = np.array(words[41 + g.N_PAD + g.N_FIRST + 1:], dtype=np.uint32).view(np.float64)
     assert len(rcp) == 41 and rcp[40] == 0.0
     assert all(rcp[k] == 1.0 / np.float64(tab[k + 1] - tab[k]) for k in range(40))
     # first[b]: the walk of MetConstants.cc:37-45 from the top of the table stops there for et = 2^(b-15)
