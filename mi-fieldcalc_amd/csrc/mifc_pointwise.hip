@@ -180,23 +180,46 @@ __device__ __forceinline__ int pw_point(const PwParams& P, const float* tab, con
     const float etd = e.value(tab) * rh;
     float tcl = s[2] * x[1];
     float qcl = MIFC_K_EPS * etd / s[4];
-    // The loop has four float divisions and one double division per trip.  A float quotient a / b is the
-    // double product a * (1/b) rounded to float whenever 1/b is good to an ulp or so: the exact quotient of
-    // two floats is never closer than 2^-49 (relative) to a rounding boundary of float, the product is
-    // within 2^-52 of it -- so / cp and / p500 become multiplications by host-made double reciprocals
-    // (d[0] = 1/cp, d[1] = 1/p500; d[1] == 0 when p500 is so large or small that quotients could be subnormal:
-    // plain divisions then) and the two / tcl share one refined reciprocal.  Bit-identical, 40 % fewer instructions.
-    const double inv_cp = P.d[0], inv_p500 = P.d[1];
+    // The loop has four float divisions and one double division per trip; none of the float ones is left as the
+    // compiler's 11-instruction expansion, and every replacement is the IEEE quotient bit for bit:
+    //   * tcl / cp, a constant divisor: q = tcl * y, r = fma(-cp, q, tcl), q + r * y with y = RN(1 / cp) -- three float
+    //     instructions.  Checked against a / 1004 for EVERY finite float a with a normal or zero quotient
+    //     (tools/verify_div_by_cp.c: 4 094 297 070 values, no mismatch); infinite, NaN and tiny tcl give a temperature
+    //     the table does not cover either way, and the loop ends there.
+    //   * / p500, a divisor fixed per call: the double product with the host-made reciprocal d[1] = 1 / p500, rounded to
+    //     float -- the exact quotient of two floats is never closer than 2^-49 (relative) to a rounding boundary of float
+    //     and the product is within 2^-52 of it (d[1] == 0 when p500 is so large or small that quotients could be
+    //     subnormal: plain division then).
+    //   * the two / tcl: the compiler's own sequence (LowerFDIV32: reciprocal, one Newton step, quotient, two residual
+    //     corrections) WITHOUT its operand scaling, and with the refined reciprocal shared by both quotients.  v_div_scale
+    //     leaves operands alone unless the divisor is subnormal or huge, the numerator nearly subnormal or the exponents
+    //     96 apart; tcl is a temperature the table covers times cp (1.7e5 .. 3.8e5, known from e2.ok()), exl is a
+    //     constant, and cplr * qcl is tested against [2^-64, 2^64) -- outside it (zero included: the sign of a zero
+    //     quotient needs v_div_fixup) that quotient is a plain division.
+    // The double division of dq keeps the refined double reciprocal (shared_reciprocal, mifc_device.h).
+    const double inv_p500 = P.d[1];
+    const float inv_cp = (float)(1.0 / (double)MIFC_K_CP);
     for (int it = 0; it < 7; ++it) { // moist adiabat, :948-960
-      const Ewt e2((float)((double)tcl * inv_cp) - MIFC_K_T0);
+      const float q0 = tcl * inv_cp;
+      const float tq = __builtin_fmaf(__builtin_fmaf(-MIFC_K_CP, q0, tcl), inv_cp, q0); // tcl / cp
+      const Ewt e2(tq - MIFC_K_T0);
       if (!e2.ok())
-        break; // from here on tcl is a temperature the table covers: positive, normal
+        break; // from here on tcl is a temperature the table covers times cp: positive, normal, far from the ends of the range
       const float esat = e2.value(tab);
       const float qsat = inv_p500 != 0. ? (float)((double)(MIFC_K_EPS * esat) * inv_p500) : MIFC_K_EPS * esat / s[3];
       float dq = qcl - qsat;
-      const double inv_tcl = shared_reciprocal((double)tcl);
-      const float a1 = (float)((double)(PW_K_CPLR * qcl) * inv_tcl);
-      const float a2 = (float)((double)PW_K_EXL * inv_tcl);
+      float rc = __builtin_amdgcn_rcpf(tcl);
+      rc = __builtin_fmaf(__builtin_fmaf(-tcl, rc, 1.0f), rc, rc);
+      auto over_tcl = [&](float a) {
+        float q = a * rc;
+        q = __builtin_fmaf(__builtin_fmaf(-tcl, q, a), rc, q);
+        return __builtin_fmaf(__builtin_fmaf(-tcl, q, a), rc, q);
+      };
+      const float num1 = PW_K_CPLR * qcl;
+      float a1 = over_tcl(num1);
+      if (__builtin_expect(!(__builtin_fabsf(num1) >= 0x1p-64f && __builtin_fabsf(num1) < 0x1p64f), 0))
+        a1 = num1 / tcl;
+      const float a2 = over_tcl(PW_K_EXL);
       const double den = 1. + (double)(a1 * a2);
       dq = (float)quotient((double)dq, den, shared_reciprocal(den));
       qcl = qcl - dq;
