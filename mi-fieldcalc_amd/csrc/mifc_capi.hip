@@ -89,6 +89,24 @@ bool ensure_levels(mifc_ctx* c, size_t nlev)
   return true;
 }
 
+// One tested level of a big field through the one-shot stencil kernels: room for their workgroups' counts (StencilParams::partials).
+// Not while a capture is recorded (the buffer is the context's ONE, calls recorded side by side would share it; and growing
+// it frees memory): those launches keep one atomic per workgroup.
+void stencil_partials(mifc_ctx* c, mifc::StencilParams& P)
+{
+  P.partials = nullptr;
+  P.partials_cap = 0;
+  if (P.every_level_all_defined || P.nlev != 1 || c->capturing)
+    return;
+  // the forms' units: 4-row (one-input operators) or 8-row (wind operators) blocks x 256-column segments; bounded from above
+  const size_t units = (size_t)(P.ny_local / 4 + 2) * (size_t)(P.nx / 256 + 1);
+  if (units < 2048)
+    return;
+  int cap = 0;
+  P.partials = partials_for(c, units * 1024, &cap);
+  P.partials_cap = P.partials ? cap : 0;
+}
+
 unsigned int* partials_for(mifc_ctx* c, size_t n_cells, int* cap)
 {
   *cap = 0;
@@ -404,6 +422,7 @@ int run_stencil(mifc_ctx* c, const StencilCall& sc, int* fdefined /* [nlev] */, 
     if (!every_all)
       MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64) * (size_t)sc.nlev, hipMemcpyDeviceToHost, c->stream));
   } else {
+    stencil_partials(c, P);
     MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
     if (!every_all)
       MIFC_HIP(c, hipMemcpyAsync(pinned_counts(c), c->d_counts, sizeof(u64) * (size_t)sc.nlev, hipMemcpyDeviceToHost, c->stream));
@@ -1730,8 +1749,9 @@ static int stencil_enqueue(mifc_ctx* c, const char* who, mifc::StencilParams& P,
     if (n_undefined_dev && !c->counts_accumulate)
       MIFC_HIP(c, hipMemsetAsync(n_undefined_dev, 0, sizeof(u64) * (size_t)P.nlev, c->stream));
   }
+  stencil_partials(c, P);
   MIFC_LAUNCH(c, mifc::launch_stencil(P, c->stream));
-  if (upload && !scratch_release(c)) // the kernel reads c->d_flags
+  if ((upload || P.partials) && !scratch_release(c)) // the kernels read c->d_flags / write and read c->d_partials
     return 0;
   return 1;
 }

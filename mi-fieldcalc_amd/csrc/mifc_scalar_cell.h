@@ -22,6 +22,7 @@ struct SRowsParams
   const unsigned char* all_defined;
   float undef;
   u64* n_undefined;
+  unsigned int* partials; // one-shot form, one big tested level: the workgroup's count goes to partials[workgroup] (StencilParams::partials)
   int ragged; // split-role form only: rows at any alignment (a width that is not a multiple of 4, unaligned fields or level strides)
 };
 

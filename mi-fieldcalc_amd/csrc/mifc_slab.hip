@@ -43,6 +43,10 @@ struct mifc_slab_plan
   bool want_graph = true, graph_failed = false;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  // one tested level of a big slab: the interior launch's workgroups leave their counts here (StencilParams::partials); the
+  // plan's own buffer, so the launch can be part of the plan's graph
+  unsigned int* d_partials = nullptr;
+  int partials_cap = 0;
 };
 
 namespace {
@@ -87,6 +91,8 @@ int launch_rows(mifc_slab_plan* p, int row_begin, int row_end)
   P.every_level_all_defined = (p->fdef == MIFC_ALL_DEFINED) ? 1 : 0;
   P.all_defined = nullptr;
   P.n_undefined = p->counts;
+  P.partials = p->d_partials; // the launches of a step follow each other on one stream
+  P.partials_cap = p->partials_cap;
   if (row_begin != 0 || row_end != p->nyl) {
     P.row_begin = row_begin;
     P.row_end = row_end;
@@ -347,6 +353,11 @@ mifc_slab_plan* mifc_slab_plan_create(mifc_ctx* c, int nx, int ny_global, int j0
   p->north = j0 > 0;
   p->south = j0 + ny_local < ny_global;
   p->want_graph = graph_wanted();
+  if (nlev == 1 && fdefined_in != MIFC_ALL_DEFINED) {
+    const size_t units = (size_t)(ny_local / 4 + 2) * (size_t)(nx / 256 + 1);
+    if (units >= 2048 && hipMalloc((void**)&p->d_partials, units * sizeof(unsigned int)) == hipSuccess)
+      p->partials_cap = (int)units; // (no buffer: one atomic per workgroup, as before)
+  }
   if (hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -375,6 +386,8 @@ void mifc_slab_plan_destroy(mifc_slab_plan* p)
     (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join)
     (void)hipEventDestroy(p->ev_join);
+  if (p->d_partials)
+    (void)hipFree(p->d_partials);
   delete p;
 }
 

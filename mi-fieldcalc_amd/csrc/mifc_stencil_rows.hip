@@ -291,8 +291,12 @@ __global__ __launch_bounds__(256) void scalar_oneshot_kernel(const SRowsParams P
         st4_stream(o1p + oo + nx, z1);
     }
   }
-  if (CHECK)
-    block_count_add(P.n_undefined ? P.n_undefined + lev : nullptr, bad); // every wave of the workgroup is on this level
+  if (CHECK) {
+    if (P.partials)
+      block_count_store(P.partials + seq, bad); // one big level: added up by launch_count_partials behind this launch
+    else
+      block_count_add(P.n_undefined ? P.n_undefined + lev : nullptr, bad); // every wave of the workgroup is on this level
+  }
 }
 
 // Level-walking form for deep batches (same design as vortdiv_levelwalk_kernel, mifc_vortdiv.hip): a workgroup
@@ -653,6 +657,9 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
     if (units <= 0x7fffffffL) {
       grid = (int)units;
       form = 0;
+      // one big level with tests: the workgroups' counts by plain stores + one small launch (StencilParams::partials)
+      if (check && prm.partials && prm.n_undefined && prm.nlev == 1 && units >= 2048 && units <= prm.partials_cap)
+        rp.partials = prm.partials;
     }
   }
 
@@ -728,6 +735,8 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
     launch_op<ST_IGWIND>(rp, check, form, grid, lds, stream);
     break;
   }
+  if (rp.partials)
+    (void)launch_count_partials(rp.partials, grid, prm.n_undefined, stream);
   return hipGetLastError();
 }
 

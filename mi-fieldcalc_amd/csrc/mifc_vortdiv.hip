@@ -89,6 +89,7 @@ struct RowsParams
   const unsigned char* all_defined;
   float undef;
   u64* n_undefined;
+  unsigned int* partials; // one-shot tiles of one or two big levels: the workgroup's count goes to partials[unit] instead (see StencilParams)
 };
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -781,7 +782,9 @@ __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsP
       const unsigned int ncompute = (unsigned int)(rows_left < RB ? rows_left : RB);
       if (atomicAdd(&s_cnt[1], 1u) + 1u == ncompute) {
         const unsigned int total = atomicAdd(&s_cnt[0], 0u);
-        if (total != 0)
+        if (P.partials)
+          P.partials[seq] = total; // always written: the slots are not zeroed beforehand
+        else if (total != 0)
           atomicAdd(P.n_undefined + lev, (u64)total);
       }
     }
@@ -1770,6 +1773,13 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.all_defined = prm.all_defined;
   rp.undef = prm.undef;
   rp.n_undefined = prm.n_undefined;
+  rp.partials = nullptr;
+  // one big level with tests: the one-shot tiles leave their counts in prm.partials and one small launch adds them up (see StencilParams)
+  auto counts_by_partials = [&](long units) {
+    const bool yes = prm.partials && prm.n_undefined && !prm.every_level_all_defined && prm.nlev == 1 && units >= 2048 && units <= prm.partials_cap;
+    rp.partials = yes ? prm.partials : nullptr;
+    return yes;
+  };
   int grid = rp.per_xcd * 8;
 
   if ((prm.out_ff || ragged) && t.K != 4)
@@ -1788,10 +1798,13 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       grid = rp.per_xcd * 8;
       const bool chk = !prm.every_level_all_defined;
       if (tiles) {
+        const bool partials = counts_by_partials(units);
         if (chk)
           hipLaunchKernelGGL((vortdiv_tile_kernel<true, true, false, true, 8, true>), dim3(grid), dim3(640), 0, stream, rp);
         else
           hipLaunchKernelGGL((vortdiv_tile_kernel<false, true, false, true, 8, true>), dim3(grid), dim3(640), 0, stream, rp);
+        if (partials)
+          (void)launch_count_partials(prm.partials, rp.n_logical, prm.n_undefined, stream);
       } else {
         if (chk)
           hipLaunchKernelGGL((vortdiv_oneshot_kernel<true, true, false, true, false, true>), dim3(grid), dim3(256), 0, stream, rp);
@@ -2013,10 +2026,13 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       rp.n_logical = (int)units;
       rp.per_xcd = (rp.n_logical + 7) / 8;
       grid = rp.per_xcd * 8;
+      const bool partials = counts_by_partials(units);
       if (prm.every_level_all_defined)
         hipLaunchKernelGGL((vortdiv_tile_kernel<false, true, true, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp);
       else
         hipLaunchKernelGGL((vortdiv_tile_kernel<true, true, true, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp);
+      if (partials)
+        (void)launch_count_partials(prm.partials, rp.n_logical, prm.n_undefined, stream);
       return hipGetLastError();
     }
     *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
@@ -2033,6 +2049,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       grid = rp.per_xcd * 8;
       const bool chk = !prm.every_level_all_defined;
       const int sel = (chk ? 4 : 0) | (rv ? 2 : 0) | (dv ? 1 : 0);
+      const bool partials = counts_by_partials(units);
       switch (sel) {
 #define TILE(C, WV, WD) \
   hipLaunchKernelGGL((vortdiv_tile_kernel<C, WV, WD, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp); \
@@ -2051,6 +2068,8 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         TILE(true, true, true);
 #undef TILE
       }
+      if (partials)
+        (void)launch_count_partials(prm.partials, rp.n_logical, prm.n_undefined, stream);
       return hipGetLastError();
     }
     *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either

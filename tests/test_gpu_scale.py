@@ -68,6 +68,80 @@ def test_config4_whole_field_4000x4000(gpu_ctx, field4000, mode, tune, mifc_env)
     assert fo[0] == m["flag_out"]
 
 
+def test_one_big_tested_level_counts_by_partials(gpu_ctx, oracle, mifc_env):
+    """One tested level of 4096 x 2100: the one-shot kernels' thousands of workgroups leave their undefined counts in a
+    partials buffer that a small launch adds up (StencilParams::partials) instead of one atomic each on the level's counter.
+    Values against the oracle, counts against the row-walking forms (one atomic per wave), for the wind operators and the
+    one-input operators, through the asynchronous entry, the synchronous one and a one-slab plan (its own buffer, graph)."""
+    import torch
+
+    import mi_fieldcalc_amd as fc
+    import mi_fieldcalc_amd.synth as synth
+
+    nx, ny = 4096, 2100
+    xm, ym, fcor = synth.grid_maps(nx, ny, h=2500.0)
+    u, v = synth.wind(nx, ny, 991)
+    z = synth.scalar_field(nx, ny, 992)
+    u, z = synth.sprinkle_undef(u, 5, 0.01), synth.sprinkle_undef(z, 6, 0.01)
+    u[700:703, :2] = cases.UNDEF
+    z[1500, -3:] = cases.UNDEF
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    du, dv, dz = dev(u[None]), dev(v[None]), dev(z[None])
+    dxm, dym, dfc = dev(xm), dev(ym), dev(fcor)
+    flags = np.array([SOME], np.int32)
+    table = [("vortdiv", du, dv, False, "wind_oneshot_tiles"), ("relvort", du, dv, False, "wind_oneshot_tiles"), ("absvort", du, dv, True, "wind_oneshot_tiles"),
+             ("gradient1", dz, None, False, "scalar_oneshot"), ("gradient3", dz, None, False, "scalar_oneshot"),
+             ("plevelgwind_ycomp", dz, None, True, "scalar_oneshot"), ("plevelgvort", dz, None, True, "scalar_oneshot"),
+             ("ilevelgwind", dz, None, True, "scalar_oneshot")]
+    for name, f0, f1, use_fc, form in table:
+        two = name in ("vortdiv", "ilevelgwind")
+        got = {}
+        for how in ("oneshot", "rows"):
+            if how == "rows":
+                mifc_env("MIFC_VORTDIV_TUNE", "R=8")
+                mifc_env("MIFC_SCALAR_ROWS_R", "8")
+            else:
+                mifc_env("MIFC_VORTDIV_TUNE", None)
+                mifc_env("MIFC_SCALAR_ROWS_R", None)
+            o0, o1 = torch.empty_like(du), (torch.empty_like(du) if two else None)
+            cnt = torch.full((1,), 777, dtype=torch.int64, device="cuda")
+            assert gpu_ctx.stencil_levels_enqueue(name, f0, f1, dxm, dym, dfc if use_fc else None, o0, o1, fdefined=flags, n_undefined=cnt), name
+            if how == "oneshot":
+                assert gpu_ctx.last_stencil_form() == form, (name, gpu_ctx.last_stencil_form())
+            else:
+                assert gpu_ctx.last_stencil_form() != form
+            torch.cuda.synchronize()
+            got[how] = (o0.cpu().numpy(), None if o1 is None else o1.cpu().numpy(), int(cnt.item()))
+        mifc_env("MIFC_VORTDIV_TUNE", None)
+        mifc_env("MIFC_SCALAR_ROWS_R", None)
+        a, b = got["oneshot"], got["rows"]
+        assert a[2] == b[2] and a[2] > 1000, (name, a[2], b[2])
+        assert _bits_equal(a[0], b[0]) and (a[1] is None or _bits_equal(a[1], b[1])), name
+        # the synchronous entry: flag from the same count
+        (s0, s1), fo = gpu_ctx.stencil_levels(name, f0, f1, dxm, dym, dfc if use_fc else None, fdefined=flags)
+        assert _bits_equal(s0.cpu().numpy(), a[0]) and fo[0] == fc.classify(a[2], gpu_ctx.stencil_count_domain(name, nx, ny)), name
+    ok, e, f = oracle.call("relvort", nx, ny, u, v, xm, ym, fdefined=SOME)
+    ok2, e2, _ = oracle.call("divergence", nx, ny, u, v, xm, ym, fdefined=SOME)
+    o0, o1 = torch.empty_like(du), torch.empty_like(du)
+    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    assert gpu_ctx.stencil_levels_enqueue("vortdiv", du, dv, dxm, dym, None, o0, o1, fdefined=flags, n_undefined=cnt)
+    torch.cuda.synchronize()
+    assert ok and ok2 and _bits_equal(o0[0].cpu().numpy(), e) and _bits_equal(o1[0].cpu().numpy(), e2)
+    assert fc.classify(int(cnt.item()), nx * ny - 2 * nx) == f
+    whole = int(cnt.item())
+    # the whole field as ONE slab of a plan: the plan's own partials buffer, inside its graph
+    uh, vh = torch.zeros((1, ny + 2, nx), device="cuda"), torch.zeros((1, ny + 2, nx), device="cuda")
+    uh[:, 1:-1], vh[:, 1:-1] = du, dv
+    rv, dg = torch.empty_like(du), torch.empty_like(du)
+    pc = torch.zeros(1, dtype=torch.int64, device="cuda")
+    plan = gpu_ctx.slab_plan(nx, ny, 0, ny, uh, vh, dxm, dym, rv, dg, fdefined_in=SOME, n_undefined=pc)
+    for _ in range(2):  # the second step replays the graph
+        plan.step()
+        torch.cuda.synchronize()
+        assert int(pc.item()) == whole and _bits_equal(rv[0].cpu().numpy(), e) and _bits_equal(dg[0].cpu().numpy(), e2)
+    plan.close()
+
+
 @pytest.mark.parametrize("mode", ["all", "some"])
 @pytest.mark.parametrize("overlap", [False, True])
 def test_config4_eight_row_slabs_4000x4000(gpu_ctx, field4000, mode, overlap):
