@@ -1104,10 +1104,14 @@ chunk_done:;
 // alignment, the last column group of a row may be partial (its trailing cells are the first cells of the next row -- exactly
 // the flat neighbours the reference's loop sees at column nx-1), and the one group whose 16 bytes would reach past the END
 // of the batch (last row of the last level) is loaded cell by cell by its loader.
-template <bool CHECK, bool NT, int TR, int NL, int PF, bool WANT_V = true, bool WANT_D = true, bool ABSV = false, bool FF = false, bool RAGGED = false>
+// JAC (round 3): the same rows of two fields in LDS are all jacobian(field1, field2) needs (:2424-2455) -- its four partials
+// are the fused pair's four differences, its test the pair's plus the other field's four values; one output, P.rv.
+template <bool CHECK, bool NT, int TR, int NL, int PF, bool WANT_V = true, bool WANT_D = true, bool ABSV = false, bool FF = false, bool RAGGED = false,
+          bool JAC = false>
 __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const RowsParams P)
 {
   static_assert(WANT_V || WANT_D, "nothing to compute");
+  static_assert(!JAC || (WANT_V && !WANT_D && !ABSV && !FF), "the Jacobian is a single-output operator");
   static_assert(!(RAGGED && FF), "the three-output form takes aligned fields only");
   static_assert(!FF || (WANT_V && WANT_D && !ABSV), "the wind speed rides on the fused pair");
   static_assert(!ABSV || (WANT_V && !WANT_D), "absvort is a single-output operator");
@@ -1345,6 +1349,20 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
       }
     }
   };
+  // the Jacobian's partials are (float)(0.5 * m * d): one float multiplication with a pre-halved map factor where every
+  // lane's halves are exact (wave-uniform, decided once per chunk; half_prod otherwise) -- see ScalarHoist, mifc_scalar_cell.h
+  float hx4[4] = {0.f, 0.f, 0.f, 0.f}, hy4[4] = {0.f, 0.f, 0.f, 0.f};
+  bool halves = false;
+  if constexpr (JAC) {
+    bool exact = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hx4[k] = 0.5f * xm4[k];
+      hy4[k] = 0.5f * ym4[k];
+      exact = exact & (__builtin_fabsf(xm4[k]) >= 0x1p-125f || xm4[k] == 0.f) & (__builtin_fabsf(ym4[k]) >= 0x1p-125f || ym4[k] == 0.f);
+    }
+    halves = __builtin_amdgcn_ballot_w64(!exact) == 0;
+  }
   int buf = 0;
   for (int lev = lev0; lev < lev1; ++lev) {
     // the LDS reads of the previous level are consumed (their values went into the stores); stores stay in flight.  The
@@ -1367,7 +1385,44 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
       }
       bool ok[4] = {true, true, true, true};
       unsigned int bad = 0;
-      if constexpr (WANT_V || CHECK) { // divergence alone still tests the vorticity's four values (:1927)
+      if constexpr (JAC) { // jacobian(field1 = u, field2 = v), :2443-2449: all eight neighbours tested, four float-rounded partials
+        const v4f un = srow[buf][slot + 1][0][lane], us = srow[buf][slot - 1][0][lane];
+        const v4f vn = srow[buf][slot + 1][1][lane], vs = srow[buf][slot - 1][1][lane];
+        const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
+        const float vcx[6] = {vW, vc.x, vc.y, vc.z, vc.w, vE};
+        bool dux[6] = {true, true, true, true, true, true}, dvx[6] = {true, true, true, true, true, true};
+        if (CHECK) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            dux[k] = __builtin_islessgreater(ucx[k], undef);
+            dvx[k] = __builtin_islessgreater(vcx[k], undef);
+          }
+        }
+        float zj[4];
+        auto cells = [&](auto halves_tag) __attribute__((always_inline)) {
+          constexpr bool HALVES = decltype(halves_tag)::value;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (CHECK)
+              ok[k] = all | (dux[k] & dux[k + 2] & dvx[k] & dvx[k + 2] & (bool)__builtin_islessgreater(us[k], undef) & (bool)__builtin_islessgreater(un[k], undef) &
+                             (bool)__builtin_islessgreater(vs[k], undef) & (bool)__builtin_islessgreater(vn[k], undef));
+            const float df1dx = HALVES ? hx4[k] * (ucx[k + 2] - ucx[k]) : half_prod(xm4[k], ucx[k + 2] - ucx[k]);
+            const float df1dy = HALVES ? hy4[k] * (un[k] - us[k]) : half_prod(ym4[k], un[k] - us[k]);
+            const float df2dx = HALVES ? hx4[k] * (vcx[k + 2] - vcx[k]) : half_prod(xm4[k], vcx[k + 2] - vcx[k]);
+            const float df2dy = HALVES ? hy4[k] * (vn[k] - vs[k]) : half_prod(ym4[k], vn[k] - vs[k]);
+            const float z = df1dx * df2dy - df1dy * df2dx;
+            zj[k] = ok[k] ? z : undef;
+            if (CHECK)
+              bad += (!ok[k] & act & (k < nvalid)) ? 1u : 0u;
+          }
+        };
+        if (halves)
+          cells(std::true_type());
+        else
+          cells(std::false_type());
+        fill_columns(zj);
+        store_rows(P.rv + (size_t)lev * P.out_stride, zj);
+      } else if constexpr (WANT_V || CHECK) { // divergence alone still tests the vorticity's four values (:1927)
         const v4f un = srow[buf][slot + 1][0][lane], us = srow[buf][slot - 1][0][lane];
         const float vcx[6] = {vW, vc.x, vc.y, vc.z, vc.w, vE};
         float zv[4];
@@ -1398,7 +1453,7 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
           store_rows(P.rv + (size_t)lev * P.out_stride, zv);
         }
       }
-      if constexpr (WANT_D) {
+      if constexpr (WANT_D && !JAC) {
         const v4f vn = srow[buf][slot + 1][1][lane], vs = srow[buf][slot - 1][1][lane];
         const float ucx[6] = {uW, uc.x, uc.y, uc.z, uc.w, uE};
         float zd[4];
@@ -1650,7 +1705,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
                       (dv && !aligned16(dv)) || prm.in_level_stride % 4 != 0 || prm.out_level_stride % 4 != 0 ||
                       (prm.op == ST_ABSVORT && prm.fcoriolis && !aligned16(prm.fcoriolis));
   // (nx % 256 == 1: the column whose value fillEdges copies into column nx-1 belongs to another workgroup)
-  if (ragged && (nx % 256 == 1 || prm.op == ST_JACOBIAN || env().has_vortdiv_tune || !env().split_roles || !env().levelwalk || !env().ragged_split || prm.out_ff))
+  if (ragged && (nx % 256 == 1 || env().has_vortdiv_tune || !env().split_roles || !env().levelwalk || !env().ragged_split || prm.out_ff))
     return hipSuccess;
   if (env().force_cell_kernel)
     return hipSuccess;
@@ -1682,7 +1737,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       // (profiles/r01/other_configs.jsonl, cold numbers).
       t.K = (small || prm.op == ST_JACOBIAN) ? 1 : 2;
     }
-    else if (prm.op != ST_JACOBIAN && (prm.op != ST_ABSVORT || (env().split_roles && !nan_undef_tested)) && prm.nlev >= kLevelWalkMinLevels && env().levelwalk) {
+    else if (((prm.op != ST_JACOBIAN && prm.op != ST_ABSVORT) || (env().split_roles && !nan_undef_tested)) && prm.nlev >= kLevelWalkMinLevels && env().levelwalk) {
       // Deep batches: tiles that stay put and walk the levels (map factors once per chunk of levels, a narrow
       // window of each array open at any time).  12-wave workgroups, 10 computed rows + 2 halo waves, chunks of
       // about 6 levels (8 in shallower batches), balanced; 3-6 % faster than the row-walking kernel on every device tried
@@ -1703,7 +1758,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         // kernel it ran before, which has no level-walking form of the first kind); relvort / divergence ALONE measure
         // the same in both forms (12 B per cell: +-1 %, the sign depends on the box -- profiles/r03/split_role_ops.txt) and
         // keep the first, MIFC_VORTDIV_TUNE="K=4,..." selects the split-role one.
-        if (env().split_roles && !nan_undef_tested && ((rv && dv) || prm.op == ST_ABSVORT || ragged)) {
+        if (env().split_roles && !nan_undef_tested && ((rv && dv) || prm.op == ST_ABSVORT || prm.op == ST_JACOBIAN || ragged)) {
           t.K = 4;
           t.D = 1;
           t.WPB = 2;
@@ -1946,7 +2001,11 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
     return hipSuccess;
   }
-  if (t.K == 4 && prm.op != ST_JACOBIAN) { // split-role level-walking tiles (loader waves / compute waves)
+  if (t.K == 4 && prm.op == ST_JACOBIAN && env().has_vortdiv_tune) { // a forced tuning: the Jacobian has the default shape only
+    *handled = false;
+    return hipSuccess;
+  }
+  if (t.K == 4) { // split-role level-walking tiles (loader waves / compute waves)
     const bool single = !(rv && dv) || rp.fc; // one output: the default shape only (and its one-level-ahead sibling)
     const int tile_rows = (single || ragged || prm.out_ff) ? 12 : ((t.RB == 6 || t.RB == 8 || t.RB == 12 || t.RB == 14) ? t.RB : 10);
     const int nchunks_lg = (t.LG > 0 && t.LG < prm.nlev) ? t.LG : prm.nlev; // levels per workgroup
@@ -1972,6 +2031,14 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     hipLaunchKernelGGL((vortdiv_split_kernel<false, true, TR_, NL_, PF_, ##__VA_ARGS__>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp)
     if (prm.out_ff) { // the fused pair plus the wind speed: the default shape
       SPLIT_AS(12, 2, 2, true, true, false, true);
+      return hipGetLastError();
+    }
+    if (prm.op == ST_JACOBIAN) { // the default shape, rows at any alignment or not
+      if (ragged) {
+        SPLIT_AS(12, 2, 2, true, false, false, false, true, true);
+      } else {
+        SPLIT_AS(12, 2, 2, true, false, false, false, false, true);
+      }
       return hipGetLastError();
     }
     if (ragged) { // rows at any alignment: the default shape

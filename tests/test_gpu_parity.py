@@ -701,7 +701,7 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc
         assert res is not None, name
         if on_device:  # the case reaches the kernel it is meant for
             if name == "jacobian":
-                want_form = "wind_rows"
+                want_form = "wind_rows" if nosplit else "wind_split"
             elif f1 is not None:
                 split = not nosplit and name in ("vortdiv", "absvort")
                 want_form = "wind_split" if split else ("wind_rows" if name == "absvort" else "wind_levelwalk")
@@ -771,7 +771,8 @@ def test_split_role_kernels_on_rows_at_any_alignment(gpu_ctx, oracle, nx, ny, nl
                 ("absvort", "absvort", u, v, True, None), ("gradient1", "gradient", z, None, False, 1), ("gradient2", "gradient", z, None, False, 2),
                 ("gradient3", "gradient", z, None, False, 3), ("gradient4", "gradient", z, None, False, 4),
                 ("plevelgwind_xcomp", "plevelgwind_xcomp", z, None, True, None), ("plevelgwind_ycomp", "plevelgwind_ycomp", z, None, True, None),
-                ("plevelgvort", "plevelgvort", z, None, True, None), ("ilevelgwind", "ilevelgwind", z, None, True, None)]
+                ("plevelgvort", "plevelgvort", z, None, True, None), ("ilevelgwind", "ilevelgwind", z, None, True, None),
+                ("jacobian", "jacobian", z, u, False, None)]
 
     for all_defined in (False, True):
         fl = flags
