@@ -22,6 +22,8 @@ struct SRowsParams
   const unsigned char* all_defined;
   float undef;
   u64* n_undefined;
+  const float *g1, *g2; // advection_split_kernel: the wind components u, v (own rows only)
+  float scale;          // ... and -3600 * hours
   unsigned int* partials; // one-shot form, one big tested level: the workgroup's count goes to partials[workgroup] (StencilParams::partials)
   int ragged; // split-role form only: rows at any alignment (a width that is not a multiple of 4, unaligned fields or level strides)
 };
@@ -216,6 +218,8 @@ __device__ __forceinline__ bool scalar_cell_hoisted(bool all, float undef, float
 } // namespace
 
 // split-role level-walking form (mifc_stencil_split.hip); rp.uB / rp.uW / rp.wpb / rp.n_logical / rp.per_xcd are set by it
+// advection (three input fields) on split-role level-walking tiles; *handled stays false where that form does not apply
+hipError_t launch_advection_split(const StencilParams& prm, hipStream_t stream, bool* handled);
 bool scalar_split_applies(int op, int nx, int ny, int nlev, bool check, float undef, bool ragged);
 hipError_t launch_scalar_split(int op, SRowsParams& rp, bool check, hipStream_t stream);
 

@@ -576,6 +576,7 @@ inline bool wind_flat4_applies(const StencilParams& prm)
 hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, bool* handled); // mifc_vortdiv.hip
 hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool* handled);  // mifc_stencil_rows.hip
 hipError_t launch_advection_oneshot(const StencilParams& prm, hipStream_t stream, bool* handled); // mifc_advection.hip
+hipError_t launch_advection_split(const StencilParams& prm, hipStream_t stream, bool* handled);   // mifc_stencil_split.hip
 
 namespace {
 struct PrepLevels
@@ -652,6 +653,10 @@ hipError_t launch_stencil(const StencilParams& prm, hipStream_t stream)
   }
   if (prm.op == ST_ADVECTION && !env().force_cell_kernel) {
     bool handled = false;
+    const hipError_t es = launch_advection_split(prm, stream, &handled); // deep batches (mifc_stencil_split.hip)
+    if (handled)
+      return es;
+    note_form("advection_oneshot");
     const hipError_t e = launch_advection_oneshot(prm, stream, &handled);
     if (handled)
       return e;

@@ -350,6 +350,195 @@ __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// ---- advection (FieldCalculations.cc:1942-1983) in the same form: a 5-point stencil on f with the wind at the centre.
+// The loaders bring the TR + 2 rows of f AND the tile's TR rows of u and of v into LDS (38 one-KiB loads per level for
+// TR = 12, 19 per loader wave); the compute waves read LDS and store -- 16 B per cell of HBM traffic, the map factors once
+// per chunk of levels (the one-shot kernel of mifc_advection.hip reads them with every level: 24 B per cell, 64 % of
+// peak on a 137-level batch).  advec = (u * 0.5 * xm * (e - w) + v * 0.5 * ym * (n - s)) * scale in double, left to right
+// (:1972); 0.5 * xm per cell once per chunk: u * (0.5 * xm) and (u * 0.5) * xm are the same exact product.
+template <bool CHECK, int TR, int NL, int PF>
+__global__ __launch_bounds__(64 * (TR + NL)) void advection_split_kernel(const SRowsParams P)
+{
+  constexpr int NB = PF + 1;               // level buffers
+  constexpr int NS = TR + 2;               // row slots of f per level: slot s holds tile row s - 1
+  constexpr int NE = NS + 2 * TR;          // ... followed by (u, v) of tile row r at NS + 2 r, NS + 2 r + 1
+  constexpr int KMAX = (NE + NL - 1) / NL; // entries per loader wave
+  static_assert(2 * NS <= 64, "the edge scalars of a level are one dword per lane");
+  __shared__ v4f srow[NB][NE][64];
+  __shared__ float sedge[NB][64]; // [buffer][2 * slot + (west | east)]
+  __shared__ unsigned int sbad[2];
+  if (CHECK && threadIdx.x < 2)
+    sbad[threadIdx.x] = 0; // ordered before the first use by the barrier of the first level
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int bid = blockIdx.x;
+  const int seq = (bid & 7) * P.per_xcd + (bid >> 3);
+  if (seq >= P.n_logical)
+    return;
+  const int ntiles = P.uB * P.uW;
+  const int lchunk = seq / ntiles;
+  const int tile = seq - lchunk * ntiles;
+  const int rblock = tile / P.uW;
+  const int wc = tile - rblock * P.uW;
+  const int lev0 = lchunk * P.wpb; // wpb: levels per chunk
+  const int lev1 = (lev0 + P.wpb < P.nlev) ? lev0 + P.wpb : P.nlev;
+  const int nx = P.nx, ny = P.ny;
+  const int first = 1 + rblock * TR; // rows 1 .. ny-2 are computed
+  const int col = wc * 256 + lane * 4;
+  const bool act = col < nx;
+  const int col_c = act ? col : nx - 4;
+  int east_col = wc * 256 + 256;
+  if (east_col > nx)
+    east_col = nx;
+
+  if (wave >= TR) {
+    // ------------------------------------------------------------------ loader
+    const int lw = wave - TR;
+    int off[KMAX], entry_of[KMAX];
+    const float* src[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      int e = lw + NL * k;
+      if (e > NE - 1)
+        e = NE - 1; // a wave with fewer entries repeats the last one (same data to the same place)
+      const int w = e - NS; // >= 0: a wind row
+      const int jr = (w < 0) ? first + e - 1 : first + (w >> 1);
+      const int j = jr < ny - 1 ? jr : ny - 1; // rows past the field: the last row, never used
+      entry_of[k] = e;
+      src[k] = (w < 0) ? P.f : ((w & 1) ? P.g2 : P.g1);
+      off[k] = j * nx + col_c; // offsets inside a level fit 32 bits (the launcher checks)
+    }
+    const int ei = (lane < 2 * NS) ? lane : 0;
+    const int ejr = first + (ei >> 1) - 1;
+    const int ej = ejr < ny - 1 ? ejr : ny - 1;
+    long e64 = (long)ej * nx + ((ei & 1) ? east_col : (wc * 256 - 1));
+    const long idx_hi = (long)nx * ny - 1;
+    e64 = e64 < 0 ? 0 : (e64 > idx_hi ? idx_hi : e64);
+    const int eoff = (int)e64;
+    auto walk = [&](auto edge_tag) __attribute__((always_inline)) {
+      constexpr bool EDGE = decltype(edge_tag)::value;
+      constexpr int L = KMAX + (EDGE ? 1 : 0); // load instructions per level of this wave
+      auto issue = [&](int lev, int b) {
+        const int l = lev < lev1 ? lev : lev1 - 1; // past the chunk: a valid address into a buffer nobody reads
+        const size_t lo = (size_t)l * P.in_stride;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src[k] + lo + off[k]),
+                                           (void __attribute__((address_space(3)))*)&srow[b][entry_of[k]][0], 16, 0, 0);
+        if (EDGE)
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(P.f + lo + eoff), (void __attribute__((address_space(3)))*)&sedge[b][0],
+                                           4, 0, 0);
+      };
+#pragma unroll
+      for (int k = 0; k < PF; ++k)
+        issue(lev0 + k, k);
+      int b_next = PF % NB;
+      auto hand_over = [&](int lev_done) { // see scalar_split_kernel
+        if (CHECK && lw == NL - 1 && P.n_undefined && lane == 0) {
+          const int q = (lev_done - lev0) & 1;
+          const unsigned int n = sbad[q];
+          if (n != 0) {
+            atomicAdd(P.n_undefined + lev_done, (u64)n);
+            sbad[q] = 0;
+          }
+        }
+      };
+      for (int lev = lev0; lev < lev1; ++lev) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((PF - 1) * L) : "memory"); // level lev has landed
+        issue(lev + PF, b_next);
+        b_next = (b_next + 1 == NB) ? 0 : b_next + 1;
+        if (lev > lev0)
+          hand_over(lev - 1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // nothing may land in LDS after the workgroup has gone
+      if (CHECK) {
+        asm volatile("s_barrier" ::: "memory"); // the compute waves' last barrier
+        if (lev1 > lev0)
+          hand_over(lev1 - 1);
+      }
+    };
+    if (lw == 0)
+      walk(std::true_type());
+    else
+      walk(std::false_type());
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute
+  const int slot = wave + 1;
+  const int j_raw = first + wave;
+  const bool computes = j_raw <= ny - 2;
+  const int j = computes ? j_raw : ny - 2;
+  const float undef = P.undef;
+  const int base = j * nx;
+  const int o = base + col_c;
+  const int oo = base + col;
+  const bool top = j == 1, bottom = j == ny - 2;
+  const bool last_in_seg = col + 4 >= east_col;
+  double a[4] = {0., 0., 0., 0.}, b[4] = {0., 0., 0., 0.};
+  if (computes) {
+    const v4f xm4 = ld4(P.xm + o), ym4 = ld4(P.ym + o);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = 0.5 * (double)xm4[k];
+      b[k] = 0.5 * (double)ym4[k];
+    }
+  }
+  const double scale = (double)P.scale;
+  int buf = 0;
+  for (int lev = lev0; lev < lev1; ++lev) {
+    bool all = true;
+    if (CHECK)
+      all = level_flag_then_barrier(P.all_defined, lev);
+    else
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (computes) {
+      const v4f fcur = srow[buf][slot][lane];
+      const v4f fn = srow[buf][slot + 1][lane], fs = srow[buf][slot - 1][lane];
+      const v4f u4 = srow[buf][NS + 2 * wave][lane], v4 = srow[buf][NS + 2 * wave + 1][lane];
+      const float We = sedge[buf][2 * slot], Ee = sedge[buf][2 * slot + 1];
+      const float fW = dpp_lower(We, fcur.w); // lane 0 keeps the west scalar
+      float fE = dpp_upper(Ee, fcur.x);       // lane 63 keeps the east scalar
+      if (last_in_seg)
+        fE = Ee;
+      const float fc6[6] = {fW, fcur.x, fcur.y, fcur.z, fcur.w, fE};
+      float z0[4];
+      unsigned int bad = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float w = fc6[k], e = fc6[k + 2], s = fs[k], n = fn[k], uc = u4[k], vc = v4[k];
+        bool ok = true;
+        if (CHECK) // :1971
+          ok = all | all_lg(undef, uc, vc, s, w, e, n);
+        const float r = (float)(((double)uc * a[k] * (double)(e - w) + (double)vc * b[k] * (double)(n - s)) * scale); // :1972
+        z0[k] = ok ? r : undef;
+        if (CHECK)
+          bad += (!ok & act) ? 1u : 0u;
+      }
+      if (col == 0) // fillEdges, column part (:65-68)
+        z0[0] = z0[1];
+      if (col + 4 == nx)
+        z0[3] = z0[2];
+      if (act) {
+        float* o0p = P.o0 + (size_t)lev * P.out_stride;
+        st4_stream(o0p + oo, z0);
+        if (top) // fillEdges, row part (:70-73)
+          st4_stream(o0p + oo - nx, z0);
+        if (bottom)
+          st4_stream(o0p + oo + nx, z0);
+      }
+      if (CHECK && P.n_undefined && !all && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+        const unsigned int n = wave_sum(bad);
+        if (lane == 0)
+          atomicAdd(&sbad[(lev - lev0) & 1], n);
+      }
+    }
+    buf = (buf + 1 == NB) ? 0 : buf + 1;
+  }
+  if (CHECK) // the last level's adds are complete: the last loader hands its total over
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct SplitShape
 {
   int tr, nl, pf, lg; // tile rows, loader waves, levels the loaders run ahead, levels per chunk (0: chosen from the batch)
@@ -520,6 +709,60 @@ hipError_t launch_scalar_split(int op, SRowsParams& rp, bool check, hipStream_t 
     launch_op<ST_IGWIND>(rp, sh, check, grid, stream);
     break;
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_advection_split(const StencilParams& prm, hipStream_t stream, bool* handled)
+{
+  *handled = false;
+  constexpr int TR = 12, NL = 2, PF = 2;
+  const int nx = prm.nx, ny = prm.ny_global;
+  if (prm.op != ST_ADVECTION || !env().split_roles || !env().levelwalk || env().force_cell_kernel)
+    return hipSuccess;
+  if (nx % 4 != 0 || nx < 8 || ny < 3 || prm.j0 != 0 || prm.ny_local != ny || prm.nlev < 3 || (long)nx * ny >= 0x7fffffffL)
+    return hipSuccess;
+  if (!prm.f0 || !prm.f1 || !prm.f2 || !prm.xmapr || !prm.ymapr || !prm.out0)
+    return hipSuccess;
+  const auto a16 = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15u) == 0; };
+  if (!a16(prm.f0) || !a16(prm.f1) || !a16(prm.f2) || !a16(prm.xmapr) || !a16(prm.ymapr) || !a16(prm.out0) || prm.in_level_stride % 4 != 0 ||
+      prm.out_level_stride % 4 != 0)
+    return hipSuccess;
+  const bool check = !prm.every_level_all_defined;
+  if (check && prm.undef != prm.undef) // one-compare tests: not for NaN as undef
+    return hipSuccess;
+  const SplitShape sh = {TR, NL, PF, 0};
+  int lpc;
+  long units;
+  if (!plan(sh, nx, ny, prm.nlev, &lpc, &units) || units < (env().levelwalk_min_units > 0 ? env().levelwalk_min_units : 768))
+    return hipSuccess;
+  SRowsParams rp{};
+  rp.nx = nx;
+  rp.ny = ny;
+  rp.nlev = prm.nlev;
+  rp.f = prm.f0;
+  rp.g1 = prm.f1;
+  rp.g2 = prm.f2;
+  rp.scale = prm.scale;
+  rp.xm = prm.xmapr;
+  rp.ym = prm.ymapr;
+  rp.o0 = prm.out0;
+  rp.in_stride = prm.in_level_stride;
+  rp.out_stride = prm.out_level_stride;
+  rp.all_defined = prm.all_defined;
+  rp.undef = prm.undef;
+  rp.n_undefined = prm.n_undefined;
+  rp.uB = (ny - 2 + TR - 1) / TR;
+  rp.uW = (nx + 255) / 256;
+  rp.wpb = lpc;
+  rp.n_logical = (int)units;
+  rp.per_xcd = (rp.n_logical + 7) / 8;
+  const int grid = rp.per_xcd * 8;
+  *handled = true;
+  note_form("advection_split");
+  if (check)
+    hipLaunchKernelGGL((advection_split_kernel<true, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
+  else
+    hipLaunchKernelGGL((advection_split_kernel<false, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
   return hipGetLastError();
 }
 

@@ -102,7 +102,7 @@ def run_case(ctx, oracle, case, set_env):
             assert fo[l] == f_e, where + (int(fo[l]), int(f_e))
 
 
-F1_SWITCHES = [("MIFC_FUSED2", [None, None, None, "0"]), ("MIFC_SHAPIRO_FUSED", [None, None, None, "0"]), ("MIFC_SHAPIRO_REGS", [None, None, "0"]),
+F1_SWITCHES = [("MIFC_LEVELWALK_MIN_UNITS", [None, "1", "1"]), ("MIFC_VORTDIV_SPLIT", [None, None, None, "0"]), ("MIFC_FUSED2", [None, None, None, "0"]), ("MIFC_SHAPIRO_FUSED", [None, None, None, "0"]), ("MIFC_SHAPIRO_REGS", [None, None, "0"]),
                ("MIFC_FUSED2_BAND", [None, None, "3", "8", "17"]), ("MIFC_FORCE_CELL_KERNEL", [None, None, None, None, "1"])]
 
 

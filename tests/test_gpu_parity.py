@@ -1201,6 +1201,44 @@ def test_stencil_levels_ex_f1_operators(gpu_ctx, oracle, nx, ny, nlev, device):
     assert gpu_ctx.stencil_levels_ex("plevelqvector", dev(z), dev(t), None, dxm, dym, dfc, level_scalars=pres, compute=7, fdefined=flags) is None
 
 
+@pytest.mark.parametrize("nx,ny,nlev", [(516, 40, 5), (1440, 27, 7), (64, 15, 3), (260, 14, 9)])
+def test_advection_level_batch_on_the_split_role_kernel(gpu_ctx, oracle, nx, ny, nlev, mifc_env):
+    """advection over a deep batch: loader waves bring f (with halo rows) and the tile's rows of u and v into LDS, compute waves
+    read LDS and store (advection_split_kernel); per-level reference call bit for bit, mixed flags, undefined values in f, u
+    and v (each one's own test), ragged last tile, a batch that ends where its allocation ends."""
+    import torch
+
+    import mi_fieldcalc_amd.synth as synth
+
+    mifc_env("MIFC_LEVELWALK_MIN_UNITS", "1")
+    xm, ym, _ = synth.grid_maps(nx, ny)
+    u, v = synth.wind(nx, ny, 77 + nx, nlev=nlev)
+    z = np.stack([synth.scalar_field(nx, ny, 800 + l) for l in range(nlev)])
+    flags = np.full(nlev, SOME, np.int32)
+    flags[0] = ALL
+    for l in range(1, nlev):
+        f = (z, u, v)[l % 3]
+        f[l] = synth.sprinkle_undef(f[l], 40 + l, 0.03)
+    v[nlev - 1, ny - 2, nx - 1] = cases.UNDEF
+    z[nlev - 1, ny - 1, nx - 2] = cases.UNDEF
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    for fl in (flags, np.full(nlev, ALL, np.int32)):
+        if fl is not flags:
+            u, v = synth.wind(nx, ny, 78 + nx, nlev=nlev)
+            z = np.stack([synth.scalar_field(nx, ny, 850 + l) for l in range(nlev)])
+        res = gpu_ctx.stencil_levels_ex("advection", dev(z), dev(u), dev(v), dev(xm), dev(ym), scalar=1.0 / 3600.0, fdefined=fl)
+        assert res is not None and gpu_ctx.last_stencil_form() == "advection_split"
+        out, fo = res
+        out = out.cpu().numpy()
+        for l in range(nlev):
+            ok, e, f = oracle.call("advection", nx, ny, z[l], u[l], v[l], xm, ym, 1.0 / 3600.0, fdefined=int(fl[l]))
+            assert ok and cases.same_bits(out[l], e, nan_payload=False), l
+            assert fo[l] == f, (l, fo[l], f)
+    mifc_env("MIFC_VORTDIV_SPLIT", "0")
+    assert gpu_ctx.stencil_levels_ex("advection", dev(z), dev(u), dev(v), dev(xm), dev(ym), scalar=1.0 / 3600.0, fdefined=fl) is not None
+    assert gpu_ctx.last_stencil_form() == "advection_oneshot"
+
+
 def test_shapiro_levels_in_place(gpu_ctx, oracle):
     import torch
 
