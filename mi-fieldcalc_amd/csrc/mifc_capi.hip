@@ -96,11 +96,13 @@ void stencil_partials(mifc_ctx* c, mifc::StencilParams& P)
 {
   P.partials = nullptr;
   P.partials_cap = 0;
-  if (P.every_level_all_defined || P.nlev != 1 || c->capturing)
+  if (P.every_level_all_defined || c->capturing)
     return;
-  // the forms' units: 4-row (one-input operators) or 8-row (wind operators) blocks x 256-column segments; bounded from above
-  const size_t units = (size_t)(P.ny_local / 4 + 2) * (size_t)(P.nx / 256 + 1);
-  if (units < 2048)
+  // the forms' units per level: 4-row (one-input one-shot), 8-row (wind one-shot tiles) or 8- to 14-row (level-walking tiles)
+  // blocks x 256-column segments; bounded from above.  Small levels keep their atomics (a few hundred per counter).
+  const size_t per_level = (size_t)(P.ny_local / 4 + 2) * (size_t)(P.nx / 256 + 1);
+  const size_t units = per_level * (size_t)P.nlev;
+  if (per_level < 2048 || units > ((size_t)1 << 24))
     return;
   int cap = 0;
   P.partials = partials_for(c, units * 1024, &cap);

@@ -266,6 +266,26 @@ __global__ __launch_bounds__(256) void count_partials_kernel(const unsigned int*
 }
 } // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void count_partials_levels_kernel(const unsigned int* __restrict__ partials, int per_level, u64* counters)
+{
+  const unsigned int* p = partials + (size_t)blockIdx.x * (size_t)per_level;
+  unsigned int s = 0;
+  for (int i = threadIdx.x; i < per_level; i += 256)
+    s += p[i];
+  block_count_add(counters + blockIdx.x, s);
+}
+} // namespace
+
+hipError_t launch_count_partials_levels(const unsigned int* partials, int per_level, int nlev, u64* counters, hipStream_t stream)
+{
+  for (int l0 = 0; l0 < nlev; l0 += 65535) { // grid limit
+    const int nl = nlev - l0 > 65535 ? 65535 : nlev - l0;
+    hipLaunchKernelGGL(count_partials_levels_kernel, dim3(nl), dim3(256), 0, stream, partials + (size_t)l0 * per_level, per_level, counters + l0);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_count_partials(const unsigned int* partials, int n, u64* counter, hipStream_t stream)
 {
   int g = (n + 2047) / 2048;

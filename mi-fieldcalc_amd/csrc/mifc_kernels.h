@@ -159,6 +159,8 @@ struct PwParams
 hipError_t launch_pointwise(const PwParams& prm, hipStream_t stream);
 // sum and number of the defined cells (cvtemp compute 3, 4)
 hipError_t launch_count_partials(const unsigned int* partials, int n, u64* counter, hipStream_t stream);
+// partials[level][unit]: one workgroup per level adds its `per_level` entries to counters[level]
+hipError_t launch_count_partials_levels(const unsigned int* partials, int per_level, int nlev, u64* counters, hipStream_t stream);
 hipError_t launch_mean_defined(const float* f, int n, int all_defined, float undef, double* sum, unsigned long long* count, hipStream_t stream);
 
 // ------------------------------------ reductions over ensemble members
@@ -254,9 +256,10 @@ struct StencilParams
   // the halo exchange is in flight.  A range must not separate a global edge row from the row
   // it is filled from (rows 0 / 1 and ny-2 / ny-1 of the whole field stay together).
   int row_begin, row_end;
-  // One or two levels of a big field, tested: the one-shot kernels' workgroups leave their counts in partials[unit] (plain
-  // stores) and launch_count_partials adds them up behind the kernel -- thousands of atomics on ONE counter address take
-  // ~5.6 ns each, one after the other (4000 x 4000: 7 800 workgroups, 44 us on top of a 65-us kernel).  nullptr / 0: atomics.
+  // Big levels (>= 2 048 workgroups per level), tested: the workgroups leave their counts in partials[level][unit] (plain
+  // stores) and launch_count_partials_levels adds them up behind the kernel -- thousands of atomics on ONE counter address
+  // (or on neighbouring counters: one cache line) take ~5 ns each, one after the other (4000 x 4000: 7 800 workgroups, 44 us
+  // on top of a 65-us kernel; 8 levels on the level-walking kernel: 196 us on top of 390).  nullptr / 0: atomics.
   unsigned int* partials = nullptr;
   int partials_cap = 0;
 };

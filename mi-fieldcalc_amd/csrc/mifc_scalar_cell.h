@@ -24,7 +24,8 @@ struct SRowsParams
   u64* n_undefined;
   const float *g1, *g2; // advection_split_kernel: the wind components u, v (own rows only)
   float scale;          // ... and -3600 * hours
-  unsigned int* partials; // one-shot form, one big tested level: the workgroup's count goes to partials[workgroup] (StencilParams::partials)
+  unsigned int* partials; // big tested levels: the workgroup's count of a level goes to partials[level][unit] (StencilParams::partials)
+  long partials_cap;      // entries of it
   int ragged; // split-role form only: rows at any alignment (a width that is not a multiple of 4, unaligned fields or level strides)
 };
 

@@ -353,10 +353,10 @@ mifc_slab_plan* mifc_slab_plan_create(mifc_ctx* c, int nx, int ny_global, int j0
   p->north = j0 > 0;
   p->south = j0 + ny_local < ny_global;
   p->want_graph = graph_wanted();
-  if (nlev == 1 && fdefined_in != MIFC_ALL_DEFINED) {
-    const size_t units = (size_t)(ny_local / 4 + 2) * (size_t)(nx / 256 + 1);
-    if (units >= 2048 && hipMalloc((void**)&p->d_partials, units * sizeof(unsigned int)) == hipSuccess)
-      p->partials_cap = (int)units; // (no buffer: one atomic per workgroup, as before)
+  if (fdefined_in != MIFC_ALL_DEFINED) {
+    const size_t per_level = (size_t)(ny_local / 4 + 2) * (size_t)(nx / 256 + 1), units = per_level * (size_t)nlev;
+    if (per_level >= 2048 && units <= ((size_t)1 << 24) && hipMalloc((void**)&p->d_partials, units * sizeof(unsigned int)) == hipSuccess)
+      p->partials_cap = (int)units; // (no buffer: one atomic per workgroup and level, as before)
   }
   if (hipStreamCreateWithFlags(&p->comm_stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking) != hipSuccess ||

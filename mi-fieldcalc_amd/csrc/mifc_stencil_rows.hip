@@ -658,7 +658,7 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
       grid = (int)units;
       form = 0;
       // one big level with tests: the workgroups' counts by plain stores + one small launch (StencilParams::partials)
-      if (check && prm.partials && prm.n_undefined && prm.nlev == 1 && units >= 2048 && units <= prm.partials_cap)
+      if (check && prm.partials && prm.n_undefined && (long)rp.uB * rp.uW >= 2048 && units <= prm.partials_cap)
         rp.partials = prm.partials;
     }
   }
@@ -703,7 +703,14 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
   note_form(form == 0 ? "scalar_oneshot" : form == 3 ? "scalar_levelwalk" : "scalar_rows");
   if (form != 0 && forced_r < 0 && scalar_split_applies(op, nx, ny, prm.nlev, check, prm.undef, false)) {
     note_form("scalar_split");
+    // big tested levels: room for the tiles' counts (the split-role launcher keeps it if the levels are big enough)
+    if (check && prm.partials) {
+      rp.partials = prm.partials;
+      rp.partials_cap = prm.partials_cap;
+    }
     const hipError_t e = launch_scalar_split(op, rp, check, stream);
+    if (e == hipSuccess && rp.partials)
+      (void)launch_count_partials_levels(rp.partials, rp.uB * rp.uW, prm.nlev, prm.n_undefined, stream);
     if (e == hipSuccess && op == ST_GRAD_X)
       count_outer_rows();
     return e != hipSuccess ? e : hipGetLastError();
@@ -736,7 +743,7 @@ hipError_t launch_scalar_rows(const StencilParams& prm, hipStream_t stream, bool
     break;
   }
   if (rp.partials)
-    (void)launch_count_partials(rp.partials, grid, prm.n_undefined, stream);
+    (void)launch_count_partials_levels(rp.partials, rp.uB * rp.uW, prm.nlev, prm.n_undefined, stream);
   return hipGetLastError();
 }
 

@@ -176,7 +176,11 @@ __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 
         if (CHECK && lw == NL - 1 && P.n_undefined && lane == 0) {
           const int q = (lev_done - lev0) & 1;
           const unsigned int n = sbad[q];
-          if (n != 0) {
+          if (P.partials) { // big levels: a plain store per workgroup and level, added up behind the launch (StencilParams::partials)
+            P.partials[(size_t)lev_done * (size_t)ntiles + tile] = n;
+            if (n != 0)
+              sbad[q] = 0;
+          } else if (n != 0) {
             atomicAdd(P.n_undefined + lev_done, (u64)n);
             sbad[q] = 0; // the next adds into this slot come after the next barrier, which this wave reaches with lgkmcnt(0)
           }
@@ -437,7 +441,11 @@ __global__ __launch_bounds__(64 * (TR + NL)) void advection_split_kernel(const S
         if (CHECK && lw == NL - 1 && P.n_undefined && lane == 0) {
           const int q = (lev_done - lev0) & 1;
           const unsigned int n = sbad[q];
-          if (n != 0) {
+          if (P.partials) {
+            P.partials[(size_t)lev_done * (size_t)ntiles + tile] = n;
+            if (n != 0)
+              sbad[q] = 0;
+          } else if (n != 0) {
             atomicAdd(P.n_undefined + lev_done, (u64)n);
             sbad[q] = 0;
           }
@@ -683,6 +691,10 @@ hipError_t launch_scalar_split(int op, SRowsParams& rp, bool check, hipStream_t 
   rp.n_logical = (int)units;
   rp.per_xcd = (rp.n_logical + 7) / 8;
   const int grid = rp.per_xcd * 8;
+  // big levels with tests: counts by plain stores (rp.partials[level][tile], set by the caller where its buffer is large
+  // enough), added up by the caller behind this launch
+  if (!(check && rp.partials && rp.n_undefined && (long)rp.uB * rp.uW >= 2048 && (long)rp.uB * rp.uW * rp.nlev <= rp.partials_cap))
+    rp.partials = nullptr;
   switch (op) {
   case ST_GRAD_X:
     launch_op<ST_GRAD_X>(rp, sh, check, grid, stream);
@@ -759,10 +771,15 @@ hipError_t launch_advection_split(const StencilParams& prm, hipStream_t stream, 
   const int grid = rp.per_xcd * 8;
   *handled = true;
   note_form("advection_split");
+  const long tiles = (long)rp.uB * rp.uW;
+  if (check && prm.partials && prm.n_undefined && tiles >= 2048 && tiles * prm.nlev <= prm.partials_cap)
+    rp.partials = prm.partials;
   if (check)
     hipLaunchKernelGGL((advection_split_kernel<true, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
   else
     hipLaunchKernelGGL((advection_split_kernel<false, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
+  if (rp.partials)
+    (void)launch_count_partials_levels(rp.partials, (int)tiles, prm.nlev, prm.n_undefined, stream);
   return hipGetLastError();
 }
 

@@ -783,7 +783,7 @@ __global__ __launch_bounds__(64 * (RB + 2)) void vortdiv_tile_kernel(const RowsP
       if (atomicAdd(&s_cnt[1], 1u) + 1u == ncompute) {
         const unsigned int total = atomicAdd(&s_cnt[0], 0u);
         if (P.partials)
-          P.partials[seq] = total; // always written: the slots are not zeroed beforehand
+          P.partials[seq] = total; // always written: the slots are not zeroed beforehand; seq = level * units per level + unit
         else if (total != 0)
           atomicAdd(P.n_undefined + lev, (u64)total);
       }
@@ -1244,7 +1244,11 @@ __global__ __launch_bounds__(64 * (TR + NL)) void vortdiv_split_kernel(const Row
         if (CHECK && !EDGE && lw == NL - 1 && P.n_undefined && lane == 0) {
           const int q = (lev_done - lev0) & 1;
           const unsigned int n = sbad[q];
-          if (n != 0) {
+          if (P.partials) { // big levels: a plain store per workgroup and level, added up behind the launch (StencilParams::partials)
+            P.partials[(size_t)lev_done * (size_t)ntiles + tile] = n;
+            if (n != 0)
+              sbad[q] = 0;
+          } else if (n != 0) {
             atomicAdd(P.n_undefined + lev_done, (u64)n);
             sbad[q] = 0; // the next adds into this slot come after the next barrier
           }
@@ -1758,7 +1762,9 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
         // kernel it ran before, which has no level-walking form of the first kind); relvort / divergence ALONE measure
         // the same in both forms (12 B per cell: +-1 %, the sign depends on the box -- profiles/r03/split_role_ops.txt) and
         // keep the first, MIFC_VORTDIV_TUNE="K=4,..." selects the split-role one.
-        if (env().split_roles && !nan_undef_tested && ((rv && dv) || prm.op == ST_ABSVORT || prm.op == ST_JACOBIAN || ragged)) {
+        // (single outputs on big tested levels too: that kernel leaves its counts in prm.partials, the first form adds them one by one)
+        const bool big_tested = prm.partials && !prm.every_level_all_defined && tiles >= 2048;
+        if (env().split_roles && !nan_undef_tested && ((rv && dv) || prm.op == ST_ABSVORT || prm.op == ST_JACOBIAN || ragged || big_tested)) {
           t.K = 4;
           t.D = 1;
           t.WPB = 2;
@@ -1830,8 +1836,10 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
   rp.n_undefined = prm.n_undefined;
   rp.partials = nullptr;
   // one big level with tests: the one-shot tiles leave their counts in prm.partials and one small launch adds them up (see StencilParams)
-  auto counts_by_partials = [&](long units) {
-    const bool yes = prm.partials && prm.n_undefined && !prm.every_level_all_defined && prm.nlev == 1 && units >= 2048 && units <= prm.partials_cap;
+  auto counts_by_partials = [&](long units_per_level, bool level_walking = false) {
+    // (the one-shot tiles index partials[unit of the launch]: level-major only in address order, lgroup == 0)
+    const bool yes = prm.partials && prm.n_undefined && !prm.every_level_all_defined && !prm.out_ff && (level_walking || rp.lgroup == 0) &&
+                     units_per_level >= 2048 && units_per_level * prm.nlev <= prm.partials_cap;
     rp.partials = yes ? prm.partials : nullptr;
     return yes;
   };
@@ -1853,13 +1861,13 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       grid = rp.per_xcd * 8;
       const bool chk = !prm.every_level_all_defined;
       if (tiles) {
-        const bool partials = counts_by_partials(units);
+        const bool partials = counts_by_partials((long)rp.uB * rp.uW);
         if (chk)
           hipLaunchKernelGGL((vortdiv_tile_kernel<true, true, false, true, 8, true>), dim3(grid), dim3(640), 0, stream, rp);
         else
           hipLaunchKernelGGL((vortdiv_tile_kernel<false, true, false, true, 8, true>), dim3(grid), dim3(640), 0, stream, rp);
         if (partials)
-          (void)launch_count_partials(prm.partials, rp.n_logical, prm.n_undefined, stream);
+          (void)launch_count_partials_levels(prm.partials, rp.uB * rp.uW, prm.nlev, prm.n_undefined, stream);
       } else {
         if (chk)
           hipLaunchKernelGGL((vortdiv_oneshot_kernel<true, true, false, true, false, true>), dim3(grid), dim3(256), 0, stream, rp);
@@ -2022,6 +2030,12 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     rp.per_xcd = (rp.n_logical + 7) / 8;
     grid = rp.per_xcd * 8;
     const bool chk = !prm.every_level_all_defined;
+    const bool partials = counts_by_partials((long)rp.uB * rp.uW, true); // big levels: counts by plain stores + one small launch
+    auto finish = [&]() {
+      if (partials)
+        (void)launch_count_partials_levels(prm.partials, rp.uB * rp.uW, prm.nlev, prm.n_undefined, stream);
+      return hipGetLastError();
+    };
     const int pf = t.D >= 2 ? 3 : (t.D == 1 ? 2 : 1); // D selects how many levels the loaders run ahead
     const int nl = (t.WPB == 2 || t.WPB == 4) ? t.WPB : (tile_rows == 10 ? 4 : 2); // WPB doubles as the number of loader waves
 #define SPLIT_AS(TR_, NL_, PF_, ...)                                                                                                       \
@@ -2031,7 +2045,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     hipLaunchKernelGGL((vortdiv_split_kernel<false, true, TR_, NL_, PF_, ##__VA_ARGS__>), dim3(grid), dim3(64 * (TR_ + NL_)), 0, stream, rp)
     if (prm.out_ff) { // the fused pair plus the wind speed: the default shape
       SPLIT_AS(12, 2, 2, true, true, false, true);
-      return hipGetLastError();
+      return finish();
     }
     if (prm.op == ST_JACOBIAN) { // the default shape, rows at any alignment or not
       if (ragged) {
@@ -2039,7 +2053,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       } else {
         SPLIT_AS(12, 2, 2, true, false, false, false, false, true);
       }
-      return hipGetLastError();
+      return finish();
     }
     if (ragged) { // rows at any alignment: the default shape
       if (rp.fc) {
@@ -2051,7 +2065,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       } else {
         SPLIT_AS(12, 2, 2, false, true, false, false, true);
       }
-      return hipGetLastError();
+      return finish();
     }
     if (single) {
       const bool pf1 = pf == 1;
@@ -2062,7 +2076,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       } else {
         if (pf1) { SPLIT_AS(12, 2, 1, false, true, false); } else { SPLIT_AS(12, 2, 2, false, true, false); }
       }
-      return hipGetLastError();
+      return finish();
     }
 #define SPLIT(TR_, NL_, PF_) SPLIT_AS(TR_, NL_, PF_)
     if (tile_rows == 6) {
@@ -2082,7 +2096,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
     }
 #undef SPLIT
 #undef SPLIT_AS
-    return hipGetLastError();
+    return finish();
   }
   if (t.K == 2 && !rp.fc && prm.op != ST_JACOBIAN && t.RB == 14 && rv && dv) { // one-shot tiles of 14 rows (16-wave workgroups)
     constexpr int RB = 14;
@@ -2093,13 +2107,13 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       rp.n_logical = (int)units;
       rp.per_xcd = (rp.n_logical + 7) / 8;
       grid = rp.per_xcd * 8;
-      const bool partials = counts_by_partials(units);
+      const bool partials = counts_by_partials((long)rp.uB * rp.uW);
       if (prm.every_level_all_defined)
         hipLaunchKernelGGL((vortdiv_tile_kernel<false, true, true, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp);
       else
         hipLaunchKernelGGL((vortdiv_tile_kernel<true, true, true, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp);
       if (partials)
-        (void)launch_count_partials(prm.partials, rp.n_logical, prm.n_undefined, stream);
+        (void)launch_count_partials_levels(prm.partials, rp.uB * rp.uW, prm.nlev, prm.n_undefined, stream);
       return hipGetLastError();
     }
     *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either
@@ -2116,7 +2130,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
       grid = rp.per_xcd * 8;
       const bool chk = !prm.every_level_all_defined;
       const int sel = (chk ? 4 : 0) | (rv ? 2 : 0) | (dv ? 1 : 0);
-      const bool partials = counts_by_partials(units);
+      const bool partials = counts_by_partials((long)rp.uB * rp.uW);
       switch (sel) {
 #define TILE(C, WV, WD) \
   hipLaunchKernelGGL((vortdiv_tile_kernel<C, WV, WD, true, RB>), dim3(grid), dim3(64 * (RB + 2)), 0, stream, rp); \
@@ -2136,7 +2150,7 @@ hipError_t launch_vortdiv_rows(const StencilParams& prm, hipStream_t stream, boo
 #undef TILE
       }
       if (partials)
-        (void)launch_count_partials(prm.partials, rp.n_logical, prm.n_undefined, stream);
+        (void)launch_count_partials_levels(prm.partials, rp.uB * rp.uW, prm.nlev, prm.n_undefined, stream);
       return hipGetLastError();
     }
     *handled = false; // a level or a launch beyond the 32-bit index range of these forms: rp was changed for them, so not the row kernel below either

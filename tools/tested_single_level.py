@@ -20,6 +20,7 @@ import mi_fieldcalc_amd.synth as synth  # noqa: E402
 
 def main():
     nx, ny = (int(a) for a in (sys.argv[1] if len(sys.argv) > 1 else "4000,4000").split(","))
+    nlev = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     dev = torch.device("cuda", 0)
     ctx = fc.Context(0)
     ctx.use_torch_stream()
@@ -27,15 +28,15 @@ def main():
     dxm, dym = torch.from_numpy(xm).to(dev), torch.from_numpy(ym).to(dev)
     sets = []
     for k in range(3):
-        u, v = synth.device_wind(nx, ny, 1, 70 + k, dev)
+        u, v = synth.device_wind(nx, ny, nlev, 70 + k, dev)
         sets.append([u, v, torch.empty_like(u), torch.empty_like(u)])
-    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(nlev, dtype=torch.int64, device=dev)
     state = {"k": 0}
 
     def run(flag):
         u, v, rv, dg = sets[state["k"] % 3]
         state["k"] += 1
-        flags = np.full(1, flag, np.int32)
+        flags = np.full(nlev, flag, np.int32)
         assert ctx.vortdiv_levels_enqueue(u, v, dxm, dym, rv, dg, fdefined=flags, n_undefined=cnt if flag != fc.ALL_DEFINED else None)
 
     def timed(flag):
@@ -53,8 +54,8 @@ def main():
             ms.append(e0.elapsed_time(e1) / 10)
         return float(np.median(ms))
 
-    alg = nx * ny * 24.0
-    print("%dx%d, one level, fused vorticity + divergence, ms per launch (cold, bursts of 10); form: see last column" % (nx, ny))
+    alg = nx * ny * (16.0 * nlev + 8.0)
+    print("%dx%d, %d level(s), fused vorticity + divergence, ms per launch (cold, bursts of 10); form: see last column" % (nx, ny, nlev))
     rows = [("ALL_DEFINED", fc.ALL_DEFINED, 0.0), ("SOME_DEFINED, clean data", fc.SOME_DEFINED, 0.0), ("SOME_DEFINED, 1 % undefined", fc.SOME_DEFINED, 0.01),
             ("SOME_DEFINED, 10 % undefined", fc.SOME_DEFINED, 0.10)]
     for name, flag, frac in rows:
