@@ -707,7 +707,7 @@ def test_stencil_levels_every_operator(gpu_ctx, oracle, nx, ny, nlev, walk, mifc
                 want_form = "wind_split" if split else ("wind_rows" if name == "absvort" else "wind_levelwalk")
             else:
                 want_form = "scalar_levelwalk" if nosplit else "scalar_split"
-            assert gpu_ctx.last_stencil_form() == want_form, (name, gpu_ctx.last_stencil_form(), want_form)
+            gpu_util.check_form(gpu_ctx, want_form, what=name)
         (o0, o1), fo = res
         o0, o1 = host(o0), host(o1)
         for l in range(nlev):
@@ -787,9 +787,9 @@ def test_split_role_kernels_on_rows_at_any_alignment(gpu_ctx, oracle, nx, ny, nl
             res = gpu_ctx.stencil_levels(name, dev(f0), dev(f1), dxm, dym, dfc if use_fc else None, fdefined=fl, out0=o0, out1=o1)
             assert res is not None, name
             if ragged_split == "1" and nx % 256 != 1:
-                assert gpu_ctx.last_stencil_form() == ("wind_split_ragged" if f1 is not None else "scalar_split_ragged"), name
+                gpu_util.check_form(gpu_ctx, "wind_split_ragged" if f1 is not None else "scalar_split_ragged", what=name)
             else:
-                assert gpu_ctx.last_stencil_form() == ("cell" if name == "gradient1" else "flat4"), name
+                gpu_util.check_form(gpu_ctx, "cell" if name == "gradient1" else "flat4", what=name)
             (r0, r1), fo = res
             r0 = r0.cpu().numpy()
             r1 = None if r1 is None else r1.cpu().numpy()
@@ -828,9 +828,9 @@ def test_vortdiv_ff_levels_three_outputs_in_one_pass(gpu_ctx, oracle, nx, ny, nl
     cnt_ff = torch.full((nlev,), 99, dtype=torch.int64, device="cuda")
     assert gpu_ctx.vortdiv_ff_levels_enqueue(du, dvv, dxm, dym, rv, dg, ff, fdefined=flags, n_undefined=cnt, n_undefined_ff=cnt_ff)
     if walk == "1" and nx % 4 == 0:
-        assert gpu_ctx.last_stencil_form() == "wind_split_ff"
+        gpu_util.check_form(gpu_ctx, "wind_split_ff")
     else:
-        assert gpu_ctx.last_stencil_form() != "wind_split_ff"
+        gpu_util.check_form(gpu_ctx, differs_from="wind_split_ff")
     torch.cuda.synchronize()
     assert cases.same_bits(rv.cpu().numpy(), rv_e, nan_payload=False) and cases.same_bits(dg.cpu().numpy(), dv_e, nan_payload=False)
     c, cf = cnt.cpu().numpy(), cnt_ff.cpu().numpy()
@@ -1227,7 +1227,8 @@ def test_advection_level_batch_on_the_split_role_kernel(gpu_ctx, oracle, nx, ny,
             u, v = synth.wind(nx, ny, 78 + nx, nlev=nlev)
             z = np.stack([synth.scalar_field(nx, ny, 850 + l) for l in range(nlev)])
         res = gpu_ctx.stencil_levels_ex("advection", dev(z), dev(u), dev(v), dev(xm), dev(ym), scalar=1.0 / 3600.0, fdefined=fl)
-        assert res is not None and gpu_ctx.last_stencil_form() == "advection_split"
+        assert res is not None
+        gpu_util.check_form(gpu_ctx, "advection_split")
         out, fo = res
         out = out.cpu().numpy()
         for l in range(nlev):
@@ -1236,7 +1237,7 @@ def test_advection_level_batch_on_the_split_role_kernel(gpu_ctx, oracle, nx, ny,
             assert fo[l] == f, (l, fo[l], f)
     mifc_env("MIFC_VORTDIV_SPLIT", "0")
     assert gpu_ctx.stencil_levels_ex("advection", dev(z), dev(u), dev(v), dev(xm), dev(ym), scalar=1.0 / 3600.0, fdefined=fl) is not None
-    assert gpu_ctx.last_stencil_form() == "advection_oneshot"
+    gpu_util.check_form(gpu_ctx, "advection_oneshot")
 
 
 def test_shapiro_levels_in_place(gpu_ctx, oracle):

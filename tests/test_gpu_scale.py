@@ -115,9 +115,9 @@ def test_big_tested_levels_count_by_partials(gpu_ctx, oracle, mifc_env, nlev):
             cnt = torch.full((nlev,), 777, dtype=torch.int64, device="cuda")
             assert gpu_ctx.stencil_levels_enqueue(name, f0, f1, dxm, dym, dfc if use_fc else None, o0, o1, fdefined=flags, n_undefined=cnt), name
             if how == "partials":
-                assert gpu_ctx.last_stencil_form() == form, (name, gpu_ctx.last_stencil_form())
+                gpu_util.check_form(gpu_ctx, form, what=name)
             else:
-                assert gpu_ctx.last_stencil_form() != form
+                gpu_util.check_form(gpu_ctx, differs_from=form, what=name)
             torch.cuda.synchronize()
             got[how] = (o0, o1, cnt.cpu().numpy().copy())
         mifc_env("MIFC_VORTDIV_TUNE", None)
