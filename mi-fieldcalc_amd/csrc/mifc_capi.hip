@@ -1456,7 +1456,7 @@ int mifc_stencil_levels_ex(mifc_ctx* c, int op, int nx, int ny, int nlev, const 
         return 0;
       dst = static_cast<float*>(c->slot[8]);
     }
-    fused = fused && mifc::env().shapiro_fused && mifc::shapiro2_fused_supported(nx, ny, d0, dst) && n % 4 == 0;
+    fused = fused && mifc::env().shapiro_fused && mifc::shapiro2_fused_supported(nx, ny, d0, dst) && (n % 4 == 0 || mifc::env().shapiro_regs);
     if (fused) {
       MIFC_HIP(c, hipMemcpyAsync(c->d_levels, order.data(), sizeof(int) * (size_t)nlev, hipMemcpyHostToDevice, c->stream));
       if (n_all > 0)

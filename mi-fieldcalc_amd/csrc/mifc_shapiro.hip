@@ -268,7 +268,12 @@ __global__ __launch_bounds__(64) void shapiro2_tile_kernel(const float* __restri
 // rows), 8 waves per SIMD instead of 13 per CU, two rows in flight per wave instead of one.  The three-row windows rotate by unrolling the row loop three times (a register move of a row
 // that is still in flight would wait for it).  The tested variant carries, instead of the unsmoothed rows, their
 // is_def bits (4 per lane and row): the x-triple mask of rows r and r-1, the row masks of rows r-3..r.
-template <bool ALL>
+// RAGGED (round 3): any width, fields and level strides at dword alignment.  Nothing here needs aligned rows but the 16-byte
+// accesses themselves: unaligned loads cost nothing, unaligned stores 25 % of their rate (profiles/r03/experiments/
+// ragged_probe.txt); the group that holds column nx-1 may hold fewer than four cells -- it is loaded from nx-4 and shifted
+// into place (never reading past the row, i.e. past the batch), keeps column nx-1 wherever it sits and stores its cells one
+// by one.  Before: four sweep launches and a mask launch over scalar cells, six times the time of this kernel.
+template <bool ALL, bool RAGGED = false>
 __global__ __launch_bounds__(64, 8) void shapiro2_regs_kernel(const float* __restrict__ src0, float* __restrict__ dst0, const int nx, const int ny,
                                                               const float undef, const int band, const int ntiles, const long level_stride,
                                                               const int* __restrict__ levels)
@@ -283,12 +288,35 @@ __global__ __launch_bounds__(64, 8) void shapiro2_regs_kernel(const float* __res
   const int xq = tile * TW - 4 + 4 * lane;
   const bool infield = xq >= 0 && xq < nx;
   const bool owned = infield && lane >= 1 && lane <= TW / 4;
-  const bool first_col = xq == 0, last_col = xq + 4 == nx; // the group holds column 0 / nx-1: the x sweeps keep them
-  const int xc = infield ? xq : (xq < 0 ? 0 : nx - 4);     // lanes outside the field load a valid address and use nothing
+  const int k_last = nx - 1 - xq;                           // 0 .. 3 in the group that holds column nx-1
+  const bool first_col = xq == 0, last_col = RAGGED ? (k_last >= 0 && k_last <= 3) : xq + 4 == nx; // the x sweeps keep columns 0 / nx-1
+  const int nvalid = (RAGGED && infield && k_last < 3) ? k_last + 1 : 4; // cells of this group inside the row
+  const int xc = (infield && nvalid == 4) ? xq : (xq < 0 ? 0 : nx - 4);   // lanes outside the field load a valid address and use nothing
   const int jb0 = bidx * band;                               // output rows [jb0, jb1)
   const int jb1 = (jb0 + band < ny) ? jb0 + band : ny;
   const int rs = jb0 - 2, re = jb1 + 1;
-  auto row_at = [&](int r) { return *reinterpret_cast<const v4f*>(src + (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + xc); };
+  struct __attribute__((packed, aligned(4))) V4Any
+  {
+    v4f v;
+  };
+  auto row_at = [&](int r) {
+    const float* p = src + (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + xc;
+    if constexpr (!RAGGED) {
+      return *reinterpret_cast<const v4f*>(p);
+    } else {
+      v4f q = reinterpret_cast<const V4Any*>(p)->v;
+      if (infield && nvalid < 4) { // loaded from column nx-4: the group's cells are the last `nvalid` of it
+        const int sh = 4 - nvalid;
+        v4f t;
+        t.x = sh == 1 ? q.y : (sh == 2 ? q.z : q.w);
+        t.y = sh == 1 ? q.z : q.w;
+        t.z = q.w;
+        t.w = q.w;
+        q = t;
+      }
+      return q;
+    }
+  };
   auto west_of = [](float keep, float x) { // lane i <- lane i-1 (lane 0 keeps `keep`); every lane is active where these run
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, keep), __builtin_bit_cast(int, x), 0x138, 0xf, 0xf, false));
   };
@@ -304,8 +332,17 @@ __global__ __launch_bounds__(64, 8) void shapiro2_regs_kernel(const float* __res
       o[k] = s2_update<ALL>(v[k + 1], v[k], v[k + 2], s, ALL || ((m >> k) & 1u) != 0);
     if (first_col)
       o.x = q.x;
-    if (last_col)
-      o.w = q.w;
+    if constexpr (RAGGED) {
+      if (last_col) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k == k_last)
+            o[k] = q[k];
+      }
+    } else {
+      if (last_col)
+        o.w = q.w;
+    }
     return o;
   };
   auto ysweep = [&](const v4f c, const v4f sth, const v4f nth, const float s, const unsigned m) {
@@ -348,8 +385,22 @@ __global__ __launch_bounds__(64, 8) void shapiro2_regs_kernel(const float* __res
     // sweep 4 (y): D(r-2)
     const int j = r - 2;
     const v4f d = (j >= 1 && j <= ny - 2) ? ysweep(c_c, c_s, c_new, -0.25f, d3 & d2 & d1) : c_c;
-    if (owned && j >= jb0 && j < jb1)
-      __builtin_nontemporal_store(d, reinterpret_cast<v4f*>(dst + (size_t)j * nx + xq));
+    if (owned && j >= jb0 && j < jb1) {
+      float* q = dst + (size_t)j * nx + xq;
+      if constexpr (!RAGGED) {
+        __builtin_nontemporal_store(d, reinterpret_cast<v4f*>(q));
+      } else if (nvalid == 4) {
+        V4Any t;
+        t.v = d;
+        *reinterpret_cast<V4Any*>(q) = t;
+      } else {
+        q[0] = d.x;
+        if (nvalid > 1)
+          q[1] = d.y;
+        if (nvalid > 2)
+          q[2] = d.z;
+      }
+    }
   };
 #pragma unroll 1
   for (int r = rs; r <= re; r += 3) {
@@ -365,7 +416,11 @@ __global__ __launch_bounds__(64, 8) void shapiro2_regs_kernel(const float* __res
 
 bool shapiro2_fused_supported(int nx, int ny, const float* src, const float* dst)
 {
-  return nx >= 4 && (nx & 3) == 0 && ny >= 3 && src != dst && (reinterpret_cast<size_t>(src) & 15u) == 0 && (reinterpret_cast<size_t>(dst) & 15u) == 0;
+  if (nx < 4 || ny < 3 || src == dst)
+    return false;
+  if (env().shapiro_regs && nx >= 8)
+    return true; // the register form takes any width and alignment (RAGGED)
+  return (nx & 3) == 0 && (reinterpret_cast<size_t>(src) & 15u) == 0 && (reinterpret_cast<size_t>(dst) & 15u) == 0;
 }
 
 hipError_t launch_shapiro2_fused(int nx, int ny, int all_defined, float undef, const float* src, float* dst, hipStream_t stream)
@@ -398,6 +453,14 @@ hipError_t launch_shapiro2_fused_levels(int nx, int ny, int all_defined, float u
       band = 128;
     const int nbands = (ny + band - 1) / band;
     const dim3 grid((unsigned)(nbands * ntiles), (unsigned)n_launch_levels);
+    const bool ragged = (nx & 3) != 0 || (reinterpret_cast<size_t>(src) & 15u) != 0 || (reinterpret_cast<size_t>(dst) & 15u) != 0 || (level_stride & 3) != 0;
+    if (ragged) {
+      if (all_defined)
+        hipLaunchKernelGGL((shapiro2_regs_kernel<true, true>), grid, dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles, level_stride, levels);
+      else
+        hipLaunchKernelGGL((shapiro2_regs_kernel<false, true>), grid, dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles, level_stride, levels);
+      return hipGetLastError();
+    }
     if (all_defined)
       hipLaunchKernelGGL((shapiro2_regs_kernel<true>), grid, dim3(64), 0, stream, src, dst, nx, ny, undef, band, ntiles, level_stride, levels);
     else
