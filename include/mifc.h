@@ -380,7 +380,7 @@ unsigned long long mifc_stencil_count_domain(int op, int nx, int ny);
 
 /* Diagnostic: the kernel form the calling thread's last stencil launch took -- "wind_split", "wind_split_ragged",
  * "wind_split_ff", "wind_levelwalk", "wind_rows", "wind_oneshot", "wind_oneshot_tiles", "scalar_split",
- * "scalar_split_ragged", "scalar_levelwalk", "scalar_rows", "scalar_oneshot", "advection_split", "advection_oneshot", "flat4", "cell"; "" before the first launch
+ * "scalar_split_ragged", "scalar_levelwalk", "scalar_rows", "scalar_oneshot", "advection_split", "advection_split_ragged", "advection_oneshot", "flat4", "cell"; "" before the first launch
  * and for the operators with launchers of their own.  The tests use it to check that a case reaches the kernel it is
  * meant for; nothing on the data path reads it.  The string is static. */
 const char* mifc_last_stencil_form(void);

@@ -570,7 +570,9 @@ __device__ __forceinline__ bool level_flag_then_barrier(const unsigned char* fla
     return false;
   }
   const unsigned long long a = (unsigned long long)(flags + lev);
-  const unsigned long long base = a & ~3ull;
+  // (wave-uniform by contract; said again here because the "s" operand below cannot take a value the compiler keeps in VGPRs)
+  const unsigned long long base = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(a >> 32)) << 32) |
+                                  (unsigned long long)((unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)a) & ~3u);
   unsigned int w;
   asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" : "=&s"(w) : "s"(base) : "memory");
   return ((w >> ((unsigned int)(a & 3ull) * 8u)) & 0xffu) != 0u;

@@ -360,7 +360,8 @@ __global__ __launch_bounds__(64 * (TR + NL), (TR + NL <= 16) ? (2 * (TR + NL) + 
 // per chunk of levels (the one-shot kernel of mifc_advection.hip reads them with every level: 24 B per cell, 64 % of
 // peak on a 137-level batch).  advec = (u * 0.5 * xm * (e - w) + v * 0.5 * ym * (n - s)) * scale in double, left to right
 // (:1972); 0.5 * xm per cell once per chunk: u * (0.5 * xm) and (u * 0.5) * xm are the same exact product.
-template <bool CHECK, int TR, int NL, int PF>
+// RAGGED: rows at any alignment, as in scalar_split_kernel.
+template <bool CHECK, int TR, int NL, int PF, bool RAGGED = false>
 __global__ __launch_bounds__(64 * (TR + NL)) void advection_split_kernel(const SRowsParams P)
 {
   constexpr int NB = PF + 1;               // level buffers
@@ -390,7 +391,8 @@ __global__ __launch_bounds__(64 * (TR + NL)) void advection_split_kernel(const S
   const int first = 1 + rblock * TR; // rows 1 .. ny-2 are computed
   const int col = wc * 256 + lane * 4;
   const bool act = col < nx;
-  const int col_c = act ? col : nx - 4;
+  const int col_c = act ? col : (RAGGED ? 0 : nx - 4);
+  const int nvalid = RAGGED ? ((nx - col) < 4 ? (nx - col) : 4) : 4; // cells of this lane's group inside the row (<= 0: none)
   int east_col = wc * 256 + 256;
   if (east_col > nx)
     east_col = nx;
@@ -399,6 +401,9 @@ __global__ __launch_bounds__(64 * (TR + NL)) void advection_split_kernel(const S
     // ------------------------------------------------------------------ loader
     const int lw = wave - TR;
     int off[KMAX], entry_of[KMAX];
+    int off_end[KMAX]; // RAGGED: the same with the group that would reach past the end of the level pulled back inside it
+    bool fix[KMAX];
+    const long last_idx = (long)nx * ny - 1;
     const float* src[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
@@ -411,6 +416,8 @@ __global__ __launch_bounds__(64 * (TR + NL)) void advection_split_kernel(const S
       entry_of[k] = e;
       src[k] = (w < 0) ? P.f : ((w & 1) ? P.g2 : P.g1);
       off[k] = j * nx + col_c; // offsets inside a level fit 32 bits (the launcher checks)
+      fix[k] = RAGGED && ((long)off[k] + 3 > last_idx);
+      off_end[k] = fix[k] ? (int)last_idx - 3 : off[k];
     }
     const int ei = (lane < 2 * NS) ? lane : 0;
     const int ejr = first + (ei >> 1) - 1;
@@ -425,13 +432,36 @@ __global__ __launch_bounds__(64 * (TR + NL)) void advection_split_kernel(const S
       auto issue = [&](int lev, int b) {
         const int l = lev < lev1 ? lev : lev1 - 1; // past the chunk: a valid address into a buffer nobody reads
         const size_t lo = (size_t)l * P.in_stride;
+        const bool at_end = RAGGED && l == P.nlev - 1; // no next level for a partial group to read into
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
-          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src[k] + lo + off[k]),
+          __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src[k] + lo + (at_end ? off_end[k] : off[k])),
                                            (void __attribute__((address_space(3)))*)&srow[b][entry_of[k]][0], 16, 0, 0);
         if (EDGE)
           __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(P.f + lo + eoff), (void __attribute__((address_space(3)))*)&sedge[b][0],
                                            4, 0, 0);
+        if constexpr (RAGGED) {
+          bool mine = false;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            mine = mine | fix[k];
+          if (at_end && __builtin_amdgcn_ballot_w64(mine) != 0) { // one workgroup of the launch, its last level
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the pulled-back copies have landed: they are overwritten now
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+              if (fix[k]) {
+                v4f q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  const long i = (long)off[k] + c;
+                  if (i <= last_idx)
+                    q[c] = (src[k] + lo)[i];
+                }
+                srow[b][entry_of[k]][lane] = q;
+              }
+            }
+          }
+        }
       };
 #pragma unroll
       for (int k = 0; k < PF; ++k)
@@ -485,7 +515,14 @@ __global__ __launch_bounds__(64 * (TR + NL)) void advection_split_kernel(const S
   const bool last_in_seg = col + 4 >= east_col;
   double a[4] = {0., 0., 0., 0.}, b[4] = {0., 0., 0., 0.};
   if (computes) {
-    const v4f xm4 = ld4(P.xm + o), ym4 = ld4(P.ym + o);
+    v4f xm4, ym4;
+    if constexpr (RAGGED) { // (a partial group reads into the next row, which exists: rows 1 .. ny-2 are computed)
+      xm4 = reinterpret_cast<const V4Any*>(P.xm + o)->v;
+      ym4 = reinterpret_cast<const V4Any*>(P.ym + o)->v;
+    } else {
+      xm4 = ld4(P.xm + o);
+      ym4 = ld4(P.ym + o);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       a[k] = 0.5 * (double)xm4[k];
@@ -521,19 +558,39 @@ __global__ __launch_bounds__(64 * (TR + NL)) void advection_split_kernel(const S
         const float r = (float)(((double)uc * a[k] * (double)(e - w) + (double)vc * b[k] * (double)(n - s)) * scale); // :1972
         z0[k] = ok ? r : undef;
         if (CHECK)
-          bad += (!ok & act) ? 1u : 0u;
+          bad += (!ok & act & (k < nvalid)) ? 1u : 0u;
       }
       if (col == 0) // fillEdges, column part (:65-68)
         z0[0] = z0[1];
-      if (col + 4 == nx)
+      if constexpr (RAGGED) { // ... for any width: the value of column nx-2 may sit in the lane below
+        const int k_last = nx - 1 - col; // 0 .. 3 in the lane that holds column nx-1
+        const float below0 = dpp_lower(z0[3], z0[3]); // every lane of the wave is here
+        if (k_last == 0)
+          z0[0] = below0;
+        else if (k_last == 1)
+          z0[1] = z0[0];
+        else if (k_last == 2)
+          z0[2] = z0[1];
+        else if (k_last == 3)
+          z0[3] = z0[2];
+      } else if (col + 4 == nx) {
         z0[3] = z0[2];
+      }
       if (act) {
         float* o0p = P.o0 + (size_t)lev * P.out_stride;
-        st4_stream(o0p + oo, z0);
-        if (top) // fillEdges, row part (:70-73)
-          st4_stream(o0p + oo - nx, z0);
-        if (bottom)
-          st4_stream(o0p + oo + nx, z0);
+        if constexpr (RAGGED) {
+          st4_any_alignment(o0p + oo, z0, nvalid);
+          if (top) // fillEdges, row part (:70-73)
+            st4_any_alignment(o0p + oo - nx, z0, nvalid);
+          if (bottom)
+            st4_any_alignment(o0p + oo + nx, z0, nvalid);
+        } else {
+          st4_stream(o0p + oo, z0);
+          if (top) // fillEdges, row part (:70-73)
+            st4_stream(o0p + oo - nx, z0);
+          if (bottom)
+            st4_stream(o0p + oo + nx, z0);
+        }
       }
       if (CHECK && P.n_undefined && !all && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {
         const unsigned int n = wave_sum(bad);
@@ -731,13 +788,15 @@ hipError_t launch_advection_split(const StencilParams& prm, hipStream_t stream, 
   const int nx = prm.nx, ny = prm.ny_global;
   if (prm.op != ST_ADVECTION || !env().split_roles || !env().levelwalk || env().force_cell_kernel)
     return hipSuccess;
-  if (nx % 4 != 0 || nx < 8 || ny < 3 || prm.j0 != 0 || prm.ny_local != ny || prm.nlev < 3 || (long)nx * ny >= 0x7fffffffL)
+  if (nx < 8 || ny < 3 || prm.j0 != 0 || prm.ny_local != ny || prm.nlev < 3 || (long)nx * ny >= 0x7fffffffL)
     return hipSuccess;
   if (!prm.f0 || !prm.f1 || !prm.f2 || !prm.xmapr || !prm.ymapr || !prm.out0)
     return hipSuccess;
   const auto a16 = [](const void* p) { return (reinterpret_cast<size_t>(p) & 15u) == 0; };
-  if (!a16(prm.f0) || !a16(prm.f1) || !a16(prm.f2) || !a16(prm.xmapr) || !a16(prm.ymapr) || !a16(prm.out0) || prm.in_level_stride % 4 != 0 ||
-      prm.out_level_stride % 4 != 0)
+  const bool ragged = nx % 4 != 0 || !a16(prm.f0) || !a16(prm.f1) || !a16(prm.f2) || !a16(prm.xmapr) || !a16(prm.ymapr) || !a16(prm.out0) ||
+                      prm.in_level_stride % 4 != 0 || prm.out_level_stride % 4 != 0;
+  // (nx % 256 == 1: the column whose value fillEdges copies into column nx-1 belongs to another workgroup)
+  if (ragged && (!env().ragged_split || nx % 256 == 1))
     return hipSuccess;
   const bool check = !prm.every_level_all_defined;
   if (check && prm.undef != prm.undef) // one-compare tests: not for NaN as undef
@@ -774,7 +833,13 @@ hipError_t launch_advection_split(const StencilParams& prm, hipStream_t stream, 
   const long tiles = (long)rp.uB * rp.uW;
   if (check && prm.partials && prm.n_undefined && tiles >= 2048 && tiles * prm.nlev <= prm.partials_cap)
     rp.partials = prm.partials;
-  if (check)
+  if (ragged) {
+    note_form("advection_split_ragged");
+    if (check)
+      hipLaunchKernelGGL((advection_split_kernel<true, TR, NL, PF, true>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
+    else
+      hipLaunchKernelGGL((advection_split_kernel<false, TR, NL, PF, true>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
+  } else if (check)
     hipLaunchKernelGGL((advection_split_kernel<true, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
   else
     hipLaunchKernelGGL((advection_split_kernel<false, TR, NL, PF>), dim3(grid), dim3(64 * (TR + NL)), 0, stream, rp);
