@@ -1523,7 +1523,7 @@ int mifc_stencil_levels_ex(mifc_ctx* c, int op, int nx, int ny, int nlev, const 
     F.undef = undef;
     F.counts = c->d_counts;
     F.level_stride = (long)n;
-    fused = fused && fused2_enabled() && mifc::fused2_supported(F) && n % 4 == 0 && 3 * (size_t)nlev <= 5 * c->cap_lev;
+    fused = fused && fused2_enabled() && mifc::fused2_supported(F) && 3 * (size_t)nlev <= 5 * c->cap_lev;
     if (fused) {
       if (!pinned_acquire(c))
         return 0;

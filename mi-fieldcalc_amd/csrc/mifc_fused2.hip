@@ -43,8 +43,8 @@
 // bit-identical, 22 % fewer instructions per row, but 126 VGPRs = 4 waves per SIMD instead of 5, and no faster
 // (0.472-0.482 against 0.465 ms, tested 0.60 against 0.58: profiles/r02/experiments/tfp_registers.txt).  Not kept.)
 //
-// Requirements (fused2_supported): nx % 4 == 0 and 16-byte aligned fields.
-// Everything else takes the multi-pass path.
+// Requirements (fused2_supported): nx >= 8.  Widths that are not a multiple of 4 and fields off the 16-byte grid take the
+// RAGGED variant of the kernel (round 3); smaller fields the multi-pass path.
 #include <cstdlib>
 
 #include "mifc_device.h"
@@ -285,7 +285,12 @@ __device__ __forceinline__ void edge_count_cells(const Fused2Params& P, const in
 // Ring depths.  One wave reads and writes its rings in program order, so a row may be replaced as soon
 // as its last read has been ISSUED: source rows r-2..r+1 are live after iteration r for TFP (its last
 // stage reads rows r-3..r-1 of the source again), r-1..r+1 for the Q-vector; intermediate rows r-3..r-1.
-template <int OP, bool CHECK>
+// RAGGED (round 3): any width, fields and level strides at dword alignment.  The tile's groups still start at multiples of four
+// COLUMNS; what changes is that a row's address is no longer a multiple of 16 bytes (unaligned 16-byte loads: free; unaligned
+// stores: 75 % of the store rate, profiles/r03/experiments/ragged_probe.txt) and that the group holding column nx-1 may hold
+// fewer than four cells: it is loaded from column nx-4 and shifted into place (never reading past the row), its fill copy of
+// column nx-2 may come from the lane below, its cells beyond the row take part in nothing and its store is 1-3 dwords.
+template <int OP, bool CHECK, bool RAGGED = false>
 __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_tile_kernel(const Fused2Params P0, const int band, const int ntiles, const int n_main)
 {
   constexpr bool TFP = OP == F2_TFP;
@@ -326,16 +331,68 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
   const bool loadable = lane < TQ && xq >= 0 && xq < nx;
   const bool owned = loadable && lane >= 1 && lane <= TW / 4;
   const int p = 4 + 4 * lane;                 // position of the group in a ring row
-  const bool fill_w = xq == 0, fill_e = xq + 4 == nx; // the group holds column 0 / column nx-1 of the field
+  const int k_last = nx - 1 - xq;             // 0 .. 3 in the group that holds column nx-1
+  const bool fill_w = xq == 0, fill_e = RAGGED ? (k_last >= 0 && k_last <= 3) : xq + 4 == nx; // the group holds column 0 / column nx-1 of the field
+  const int nvalid = (RAGGED && loadable && k_last < 3) ? k_last + 1 : 4; // cells of this group inside the row
+  const int k_e = RAGGED ? k_last : 3;        // where column nx-1 sits in the group that holds it
   const float undef = P.undef;
+  struct __attribute__((packed, aligned(4))) V4Any
+  {
+    v4f v;
+  };
+  // a group of a row from global memory: aligned 16 bytes, or (RAGGED) 16 bytes at any dword; the partial group at the end of a
+  // row comes from column nx-4, its cells shifted to the front
+  auto ldg = [&](const float* q) __attribute__((always_inline)) {
+    if constexpr (!RAGGED) {
+      return ld4(q);
+    } else {
+      const v4f u = reinterpret_cast<const V4Any*>(q)->v;
+      float4 v = make_float4(u.x, u.y, u.z, u.w);
+      if (nvalid < 4) {
+        const int sh = 4 - nvalid;
+        float4 t;
+        t.x = sh == 1 ? v.y : (sh == 2 ? v.z : v.w);
+        t.y = sh == 1 ? v.z : v.w;
+        t.z = v.w;
+        t.w = v.w;
+        v = t;
+      }
+      return v;
+    }
+  };
+  // fillEdges of a row held as four cells per lane: column 0 <- column 1, column nx-1 <- column nx-2 (RAGGED: wherever it sits;
+  // with one cell in the group the value comes from the lane below, which every caller has active)
+  auto fill_cols = [&](float (&z)[4]) __attribute__((always_inline)) {
+    if constexpr (RAGGED) {
+      const float below = from_lower_lane(z[3], z[3]);
+      if (fill_w)
+        z[0] = z[1];
+      if (fill_e) {
+        if (k_last == 0)
+          z[0] = below;
+        else if (k_last == 1)
+          z[1] = z[0];
+        else if (k_last == 2)
+          z[2] = z[1];
+        else
+          z[3] = z[2];
+      }
+    } else {
+      if (fill_w)
+        z[0] = z[1];
+      if (fill_e)
+        z[3] = z[2];
+    }
+  };
 
   const int jb0 = 1 + bidx * band;
   const int jb1 = (jb0 + band < ny - 1) ? jb0 + band : ny - 1;
   const int rs = jb0 - 2, re = jb1 + 1;
 
-  const size_t ccol = (size_t)(loadable ? xq : tile * TW); // other lanes load a valid address and use nothing
+  // other lanes load a valid address and use nothing (RAGGED: the last four columns of the row, like the partial group)
+  const size_t ccol = RAGGED ? (size_t)((loadable && nvalid == 4) ? xq : nx - 4) : (size_t)(loadable ? xq : tile * TW);
   if (loadable && rs >= 0)
-    *reinterpret_cast<float4*>(ringA + (rs % RA) * TS + p) = CANON ? canon_nan4(ld4(P.a + (size_t)rs * nx + ccol), undef) : ld4(P.a + (size_t)rs * nx + ccol);
+    *reinterpret_cast<float4*>(ringA + (rs % RA) * TS + p) = CANON ? canon_nan4(ldg(P.a + (size_t)rs * nx + ccol), undef) : ldg(P.a + (size_t)rs * nx + ccol);
   unsigned int n1 = 0, n2 = 0, n2c = 0;
 
   struct RowMaps // what a lane keeps of a row beyond the iteration that loads it: map factors, and the Q-vector's temperature
@@ -358,12 +415,12 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
     const bool load_a = r < re && r + 1 >= 0 && r + 1 < ny;
     const size_t row_a = (size_t)(r + 1 < 0 ? 0 : (r + 1 > ny - 1 ? ny - 1 : r + 1)) * nx + ccol;
     const size_t row_m = (size_t)(r < 0 ? 0 : (r > ny - 1 ? ny - 1 : r)) * nx + ccol;
-    const float4 pa = ld4(P.a + row_a); // in flight until the end of the iteration: A(r+1), t(r), maps(r)
-    m_new.xm = ld4(P.xmapr + row_m);
-    m_new.ym = ld4(P.ymapr + row_m);
+    const float4 pa = ldg(P.a + row_a); // in flight until the end of the iteration: A(r+1), t(r), maps(r)
+    m_new.xm = ldg(P.xmapr + row_m);
+    m_new.ym = ldg(P.ymapr + row_m);
     if (!TFP) {
-      m_new.fc = ld4(P.fcoriolis + row_m);
-      m_new.t = ld4(P.t + row_m);
+      m_new.fc = ldg(P.fcoriolis + row_m);
+      m_new.t = ldg(P.t + row_m);
     }
 
     // ---- stage A: intermediate row y = r-1, for every group the wave holds (halo groups included)
@@ -385,14 +442,11 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
         for (int k = 0; k < 4; ++k) {
           bool ok;
           g[k] = tfp_absdelt<CHECK, CANON>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], undef, ok);
-          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3); // counted by edge_count_cells
-          if (counted && !edge_cell && !ok)
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == k_e); // counted by edge_count_cells
+          if (counted && !edge_cell && !ok && k < nvalid)
             ++n1;
         }
-        if (fill_w)
-          g[0] = g[1];
-        if (fill_e)
-          g[3] = g[2];
+        fill_cols(g);
         st4(mid0 + (y % 3) * TS + p, g);
       } else {
         float fc[4], ug[4], vg[4];
@@ -400,14 +454,8 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           qvec_gwind<CHECK>(sv[k], cv[k], cv[k + 2], nv[k], xm[k], ym[k], fc[k], undef, ug[k], vg[k]);
-        if (fill_w) {
-          ug[0] = ug[1];
-          vg[0] = vg[1];
-        }
-        if (fill_e) {
-          ug[3] = ug[2];
-          vg[3] = vg[2];
-        }
+        fill_cols(ug);
+        fill_cols(vg);
         st4(mid0 + (y % 3) * TS + p, ug);
         st4(mid1 + (y % 3) * TS + p, vg);
       }
@@ -458,8 +506,8 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
           o[k] = tfp_point<CHECK, CANON>(ts[k], tc[k], tc[k + 2], tn[k], gs[k], gc[k], gc[k + 1], gc[k + 2], gn[k], xm[k], ym[k], undef, ok, by_test);
           // the cells of columns 0 / nx-1 need wrapped neighbours for their tests: the edge kernel counts
           // them -- unless nothing is tested, then |grad| != 0 of the filled value is all there is
-          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
-          if (!(CHECK && edge_cell)) {
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == k_e);
+          if (!(CHECK && edge_cell) && k < nvalid) {
             n2 += ok ? 0u : 1u;
             if (by_test)
               ++n2c;
@@ -486,17 +534,16 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
           bool ok;
           o[k] = qvec_point<OP>(us[k], uc[k], uc[k + 2], un[k], vs[k], vc[k], vc[k + 2], vn[k], ts[k], tc[k], tc[k + 2], tn[k], xm[k], ym[k], P.scale,
                                 P.scale2, undef, ok);
-          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == 3);
-          if (!edge_cell)
+          const bool edge_cell = (fill_w && k == 0) || (fill_e && k == k_e);
+          if (!edge_cell && k < nvalid)
             n2 += ok ? 0u : 1u;
         }
       }
-      // fillEdges on the result: columns, then rows 0 / ny-1
-      if (fill_w)
-        o[0] = o[1];
-      if (fill_e)
-        o[3] = o[2];
     }
+    // fillEdges on the result: columns (every lane that holds a group is here: the value may come from the lane below), then
+    // rows 0 / ny-1 with the stores
+    if (row_b && lane < TQ)
+      fill_cols(o);
     // rows that were in flight since the top of the iteration; the explicit vmcnt(0) (all paths,
     // loads only by now) keeps the compiler from waiting again -- behind the store -- at the loop edge
     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -509,11 +556,26 @@ __global__ __launch_bounds__(64, (OP == F2_TFP && !CHECK) ? 5 : 4) void fused2_t
       t_south = m_b.t; // row r-2 is row (r+1)-3
     if (have_row) {
       const v4f q = {o[0], o[1], o[2], o[3]};
-      __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)j * nx + xq));
+      auto put = [&](float* at) __attribute__((always_inline)) {
+        if constexpr (!RAGGED) {
+          __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(at));
+        } else if (nvalid == 4) {
+          V4Any t;
+          t.v = q;
+          *reinterpret_cast<V4Any*>(at) = t;
+        } else {
+          at[0] = o[0];
+          if (nvalid > 1)
+            at[1] = o[1];
+          if (nvalid > 2)
+            at[2] = o[2];
+        }
+      };
+      put(P.out + (size_t)j * nx + xq);
       if (j == 1)
-        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + xq));
+        put(P.out + xq);
       if (j == ny - 2)
-        __builtin_nontemporal_store(q, reinterpret_cast<v4f*>(P.out + (size_t)(ny - 1) * nx + xq));
+        put(P.out + (size_t)(ny - 1) * nx + xq);
     }
   };
   for (int r = rs; r <= re; r += 3) {
@@ -590,7 +652,12 @@ hipError_t launch(const Fused2Params& p, hipStream_t stream)
         q.scale2_lev = p.scale2_lev ? p.scale2_lev + l0 : nullptr;
       }
     }
-    hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(n_main + n_edge), (unsigned)n), dim3(64), 0, stream, q, band, ntiles, n_main);
+    const bool ragged = (p.nx & 3) != 0 || !aligned16(p.a) || !aligned16(p.xmapr) || !aligned16(p.ymapr) || !aligned16(p.out) ||
+                        (p.op != F2_TFP && (!aligned16(p.t) || !aligned16(p.fcoriolis))) || (p.n_launch_levels > 0 && (p.level_stride & 3) != 0);
+    if (ragged)
+      hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK, true>), dim3((unsigned)(n_main + n_edge), (unsigned)n), dim3(64), 0, stream, q, band, ntiles, n_main);
+    else
+      hipLaunchKernelGGL((fused2_tile_kernel<OP, CHECK>), dim3((unsigned)(n_main + n_edge), (unsigned)n), dim3(64), 0, stream, q, band, ntiles, n_main);
   }
   return hipGetLastError();
 }
@@ -613,15 +680,15 @@ hipError_t launch_division_check(const float* a, const float* b, const float* g,
 
 bool fused2_supported(const Fused2Params& p)
 {
-  if (p.nx < 4 || (p.nx & 3) || p.ny < 3)
+  if (p.nx < 8 || p.ny < 3) // (any width from 8 columns on, any dword alignment: the RAGGED variant)
+    return false;
+  if ((p.nx & 3) != 0 && p.nx % TW == 1) // column nx-1 alone in a tile: the column its fill copy comes from belongs to another wave
     return false;
   if ((long)((p.nx + TW - 1) / TW) * ((p.ny - 2 + 3) / 4) + 256 >= 0x7fffffffL) // workgroups of the launch
     return false;
   if (!p.a || !p.xmapr || !p.ymapr || !p.out || !p.counts)
     return false;
-  if (!aligned16(p.a) || !aligned16(p.xmapr) || !aligned16(p.ymapr) || !aligned16(p.out))
-    return false;
-  if (p.op != F2_TFP && (!p.t || !p.fcoriolis || !aligned16(p.t) || !aligned16(p.fcoriolis)))
+  if (p.op != F2_TFP && (!p.t || !p.fcoriolis))
     return false;
   return true;
 }

@@ -18,7 +18,7 @@ import cases  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 ALL, SOME = cases.ALL_DEFINED, cases.SOME_DEFINED
-WIDTHS = [8, 9, 12, 17, 33, 64, 100, 252, 255, 256, 257, 258, 260, 263, 511, 512, 513, 516, 770, 949, 1000, 1023, 1024, 1025, 1029, 1440, 1443]
+WIDTHS = [8, 9, 12, 17, 33, 64, 100, 241, 252, 255, 256, 257, 258, 260, 263, 511, 512, 513, 516, 770, 949, 1000, 1023, 1024, 1025, 1029, 1440, 1443]
 SWITCHES = [("MIFC_LEVELWALK_MIN_UNITS", [None, "1", "1", "1"]), ("MIFC_RAGGED_SPLIT", [None, None, "0"]), ("MIFC_VORTDIV_SPLIT", [None, None, None, "0"]),
             ("MIFC_VORTDIV_LEVELWALK", [None, None, None, "0"]), ("MIFC_FORCE_CELL_KERNEL", [None, None, None, None, "1"]),
             ("MIFC_SCALAR_SPLIT_TUNE", [None, None, "TR=14,NL=2,PF=2", "TR=12,NL=2,PF=3,LG=2", "TR=8,NL=2,PF=2,LG=3"])]
