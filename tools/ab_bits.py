@@ -51,6 +51,11 @@ def dump(path):
             r = ctx.hlevelhum(t, q if compute in (1, 3, 5, 7, 9, 11) else rh2, ps, 10.0, 0.9, "1", compute, fdefined=flag)
             if r is not None:
                 out["hlevelhum_%d_%s" % (compute, tag)] = r[0]
+        for compute in range(1, 13):
+            for pres in (850.0, 1e-30, 0.0):
+                r = ctx.plevelhum(t, q if compute in (1, 3, 5, 7, 9, 11) else rh2, pres, "1", compute, fdefined=flag)
+                if r is not None:
+                    out["plevelhum_%d_%g_%s" % (compute, pres, tag)] = r[0]
         for compute in range(1, 6):
             r = ctx.hleveltemp(t, ps, 10.0, 0.9, "1", compute, fdefined=flag)
             if r is not None:
