@@ -1002,6 +1002,47 @@ def test_gradients_with_map_factors_whose_halves_are_inexact(gpu_ctx, oracle, ti
                 assert fo[l] == f_e, (compute, l)
 
 
+@pytest.mark.parametrize("where", ["row 11", "rows 3 and 20", "scattered", "everywhere"])
+@pytest.mark.parametrize("nx", [516, 949])
+def test_two_stage_kernels_with_map_factors_whose_halves_are_inexact(gpu_ctx, oracle, where, nx):
+    """thermalFrontParameter and plevelqvector: the float-rounded partials (float)(0.5 * m * d) of both stages (half_prod) with map
+    factors below 2^-125 -- where 0.5f * m is not exact -- in one row, in two rows, scattered, everywhere, next to fields of
+    1e30 .. 1e37, so that the products are ordinary numbers and a wrongly halved factor shows.  (A form of the kernel that kept
+    pre-halved map rows while they were exact passed this and was 5 % faster on one of the two operators: not kept.)"""
+    ny, nlev = 31, 3
+    rng = np.random.default_rng(78)
+    import mi_fieldcalc_amd.synth as synth
+
+    xm, ym, fcor = synth.grid_maps(nx, ny)
+    small = np.array([1e-39, 2.0 ** -126, 3.0 * 2.0 ** -127, 2.0 ** -149, 1.1754942e-38, 2.0 ** -125, -(2.0 ** -126)], np.float32)
+    pick = np.zeros((ny, nx), bool)
+    if where == "row 11":
+        pick[11, nx // 3] = True
+    elif where == "rows 3 and 20":
+        pick[3, 5] = pick[20, nx - 2] = True
+    elif where == "scattered":
+        pick = rng.random((ny, nx)) < 0.02
+    else:
+        pick[:] = True
+    xm = np.where(pick, rng.choice(small, (ny, nx)), xm).astype(np.float32)
+    ym = np.where(pick[::-1], rng.choice(small, (ny, nx)), ym).astype(np.float32)
+    z = (rng.standard_normal((nlev, ny, nx)) * 10.0 ** rng.uniform(30, 37, (nlev, ny, nx))).astype(np.float32)
+    t = (250.0 + rng.standard_normal((nlev, ny, nx)) * 10.0 ** rng.uniform(28, 33, (nlev, ny, nx))).astype(np.float32)
+    flags = np.array([ALL, SOME, SOME], np.int32)
+    z[1, 7:9, 10:20] = cases.UNDEF
+    pres = np.array([850.0, 700.0, 500.0], np.float32)
+    with np.errstate(all="ignore"):
+        out, fo = gpu_ctx.stencil_levels_ex("thermalFrontParameter", z, xmapr=xm, ymapr=ym, fdefined=flags)
+        for l in range(nlev):
+            ok, e, f = oracle.call("thermalFrontParameter", nx, ny, z[l], xm, ym, fdefined=int(flags[l]))
+            assert ok and cases.same_bits(out[l], e, nan_payload=False) and fo[l] == f, ("tfp", l)
+        for c in (1, 2, 3, 4):
+            out, fo = gpu_ctx.stencil_levels_ex("plevelqvector", z, t, None, xm, ym, fcor, level_scalars=pres, compute=c, fdefined=flags)
+            for l in range(nlev):
+                ok, e, f = oracle.call("plevelqvector", nx, ny, z[l], t[l], xm, ym, fcor, float(pres[l]), c, fdefined=int(flags[l]))
+                assert ok and cases.same_bits(out[l], e, nan_payload=False) and fo[l] == f, ("qvector", c, l)
+
+
 @pytest.mark.parametrize("nx,ny", [(64, 24), (1440, 37), (260, 9)])
 def test_gradient_x_counts_the_outer_rows(gpu_ctx, oracle, nx, ny):
     """gradient compute=1 tests and counts over the flat cells 1 .. nx*ny-2 (FieldCalculations.cc:2013-2021): rows 0 and ny-1
