@@ -171,6 +171,41 @@ def run_f1_case(ctx, oracle, case, set_env):
     check("shapiro", ctx.stencil_levels_ex("shapiro2_filter", dev(z), fdefined=flags), lambda l: oracle.call("shapiro2_filter", nx, ny, z[l], fdefined=int(flags[l])))
 
 
+def check_seeded_case(ctx, oracle, case, device):
+    """One case of tests/cases.py (any operator family) against the CPU checker, as test_gpu_parity.py judges it."""
+    import gpu_util
+
+    ok_e, out_e, flag_e = cases.run_cpu(oracle, case)
+    ok, out, flag = gpu_util.run_gpu(ctx, case, device=device)
+    assert ok == ok_e, case["label"]
+    if not ok_e:
+        return
+    exact = not gpu_util.uses_device_powf(case)
+    outs_e = list(out_e) if isinstance(out_e, tuple) else [out_e]
+    outs = list(out) if isinstance(out, tuple) else [out]
+    for a, b in zip(outs, outs_e):
+        gpu_util.compare(case, np.asarray(a), np.asarray(b), exact)
+    assert flag == flag_e, "%s: flag %d vs %d" % (case["label"], flag, flag_e)
+
+
+def run_grid_case(ctx, oracle, index):
+    """The seeded cases of the elementwise operators, the pointwise catalogue and the ensemble reductions on a random grid:
+    cell counts that are not multiples of 4 (the scalar tail launch), one row, one column, host or device memory."""
+    rng = np.random.default_rng(0xE7150000 + index)
+    nx = int(rng.choice([1, 2, 3, 5, 8, 17, 63, 64, 65, 127, 250, 257, 511]))
+    ny = int(rng.choice([1, 2, 3, 4, 7, 16, 33, 61]))
+    device = bool(rng.integers(2))
+    kind = int(rng.integers(3))
+    gen = (cases.ewise_cases, cases.catalogue_cases, cases.ensemble_cases)[kind]
+    for case in gen(grids=((nx, ny),)):
+        check_seeded_case(ctx, oracle, case, device)
+
+
+@pytest.mark.parametrize("index", range(24))
+def test_seeded_operator_cases_on_random_grids(gpu_ctx, oracle, index):
+    run_grid_case(gpu_ctx, oracle, index)
+
+
 @pytest.mark.parametrize("index", range(64))
 def test_random_stencil_batches_equal_the_reference(gpu_ctx, oracle, index, mifc_env):
     run_case(gpu_ctx, oracle, make_case(index), mifc_env)
@@ -206,6 +241,11 @@ if __name__ == "__main__":
         for name in touched:
             os.environ.pop(name, None)
         run_f1_case(ctx, orc, make_f1_case(i), set_env)
+        if i % 10 == 0:
+            for name in touched:
+                os.environ.pop(name, None)
+            ctx.reload_env()
+            run_grid_case(ctx, orc, i)
         if (i - first) % 250 == 249:
             print("%d cases of each kind passed" % (i - first + 1), flush=True)
     print("all %d + %d cases passed" % (n, n))
