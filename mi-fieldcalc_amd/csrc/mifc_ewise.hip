@@ -315,9 +315,15 @@ hipError_t launch_ewise_op(const EwiseParams& prm, hipStream_t stream)
     // 0.343 -> 0.295 ms, hlevelhum 0.475 -> 0.397) and than one trip each; the variants that stage BOTH tables
     // (humidity from potential temperature) are the exception -- their time grows with the number of workgroups
     // (0.51 ms at 4 096, 2.3 ms at 65 536) -- and keep the small grid.
+    // Round 3, with the leaner lookups (profiles/r03/experiments/ewise_grid_caps.txt, two A/B passes in one process pair): the
+    // variants that stage both tables no longer pay for more workgroups (alevelhum 0.473 ms at 4 096, 0.434 at 32 768, 0.452
+    // at 65 536); the dew-point variants (more arithmetic per trip) and the pressure-level ones (two inputs) run 8-9 % faster
+    // with 32 768 workgroups than with 65 536 (hlevelhum T,q->Td 0.478 -> 0.438, plevelhum 0.382 -> 0.348); hleveltemp,
+    // hlevelhum T,q->RH and cvhum are 4-10 % faster with 65 536 and keep them.
     const bool tables = ewise_needs_ewt(prm) || ewise_needs_pow(prm);
     const bool both = ewise_needs_ewt(prm) && ewise_needs_pow(prm);
-    int cap = both ? 256 * 16 : (tables ? 256 * 256 : 0x7fffffff);
+    const bool dew_point = (prm.op == EW_HUM) && (prm.kind == HUM_Q_TD || prm.kind == HUM_RH_TD);
+    int cap = !tables ? 0x7fffffff : ((both || dew_point || prm.psrc == PS_SCALAR) ? 256 * 128 : 256 * 256);
     if (env().ewise_max_blocks > 0)
       cap = env().ewise_max_blocks;
     const int grid = grid_for(n4, block, cap);
