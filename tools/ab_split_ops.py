@@ -77,7 +77,9 @@ def main():
     counts = torch.zeros(nlev, dtype=torch.int64, device=dev)
     ctx.use_torch_stream()
     # "pf1": the wind operators' split-role kernel with the loaders ONE level ahead (two level buffers: two workgroups per CU)
-    modes = [("old", {"MIFC_VORTDIV_SPLIT": "0"}), ("split", {}), ("pf1", {"MIFC_VORTDIV_TUNE": "K=4,RB=12,D=0,WPB=2,LG=6"})]
+    # "k4": the wind operators' split-role kernel two levels ahead, forced also where the default keeps the first level-walking form (single outputs)
+    modes = [("old", {"MIFC_VORTDIV_SPLIT": "0"}), ("split", {}), ("pf1", {"MIFC_VORTDIV_TUNE": "K=4,RB=12,D=0,WPB=2,LG=6"}),
+             ("k4", {"MIFC_VORTDIV_TUNE": "K=4,RB=12,D=1,WPB=2,LG=6"})]
     for sh in [s for s in args.shapes.split(";") if s]:
         modes.append((sh, {"MIFC_SCALAR_SPLIT_TUNE": sh}))
     keys = sorted({k for _, e in modes for k in e})
@@ -101,7 +103,7 @@ def main():
                 raise RuntimeError(ctx.last_error())
 
         res = {m: [] for m, _ in modes}
-        use = [(m, e) for m, e in modes if (scalar and m != "pf1") or (not scalar and m in ("old", "split", "pf1"))]
+        use = [(m, e) for m, e in modes if (scalar and m not in ("pf1", "k4")) or (not scalar and m in ("old", "split", "pf1", "k4"))]
         for m, e in use:
             select(e)
             for _ in range(args.burst):
